@@ -1,0 +1,158 @@
+/* C ABI of libbasd_hip.so -- the MI355X (gfx950) kernels behind the BASD loss path.
+ *
+ * The reference (indrajeetadityaroy9/vit-inductive-bias-distillation) is pure Python: its
+ * "FFI" for this path is the set of torch operator call sites in src/losses/*.py.  Each entry
+ * point below replaces one (or a fused group) of those call sites; the file:line it stands in
+ * for is quoted on every declaration (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory unless marked host; sizes/strides are in ELEMENTS;
+ *   - no entry point allocates, frees or synchronises; all work is queued on `stream`
+ *     (pass torch.cuda.current_stream().cuda_stream); scratch buffers are caller-provided;
+ *   - return value: 0 = ok, <0 = invalid argument / unsupported shape (BASD_E*), >0 = hipError_t;
+ *   - dtype codes: 0 = fp32, 1 = bf16 (inputs only; all arithmetic and outputs are fp32/fp64);
+ *   - entry points are re-entrant and keep no global mutable state.
+ */
+#ifndef BASD_HIP_H
+#define BASD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define BASD_OK 0
+#define BASD_EINVAL (-1)
+#define BASD_EUNSUPPORTED (-2)
+#define BASD_DTYPE_F32 0
+#define BASD_DTYPE_BF16 1
+
+/* ---- dense contractions (fp32 MFMA, v_mfma_f32_32x32x2_f32) ------------------------------- */
+
+/* C[z] (M x N, ldc) = scale * A[z] (M x K) * B[z]^T (N x K).
+ * replaces: `tokens.reshape(-1, D_t) @ proj_t.T`  layer_selector.py:72,:135;
+ *           `features @ features.T / M`           layer_selector.py:15;
+ *           `U_s.T @ U_t`                          layer_selector.py:99.
+ * A element (m, k): a + z*a_batch_stride + (m / a_rows_per_batch)*a_sb + (m % a_rows_per_batch)*a_sn + k*a_sd
+ * (so (B, N, D) token views, CLS-sliced or channel-major, are consumed in place). B: fp32 row-major. */
+int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, int a_rows_per_batch,
+                 long a_batch_stride, const float* b, long ldb, long b_batch_stride, int M, int N, int K, int batch,
+                 float* c, long ldc, long c_batch_stride, float scale, hipStream_t stream);
+
+/* Suggested split count over the contraction rows for basd_gemm_tn. */
+int basd_gemm_tn_splits(int krows);
+
+/* C[z] (M x N) = scale * (A[z] - 1 mean_a^T)^T (B[z] - 1 mean_b^T), contraction over `krows` rows.
+ * replaces: `features.T @ features / M`  layer_selector.py:13  (mean = NULL, scale = 1/M) and the
+ *           centred z^T z behind `torch.linalg.svd(z - z.mean(0))`  layer_selector.py:35-36, :90-92;
+ *           also the per-sample K' A' product of the Procrustes backward (batch > 1, splits = 1).
+ * `slabs`: batch*splits*M*N floats of scratch when splits > 1 (deterministic split-K reduction). */
+int basd_gemm_tn(const void* a, const void* b, int dtype, long a_sb, long a_sn, long a_sd, long a_batch_stride,
+                 long b_sb, long b_sn, long b_sd, long b_batch_stride, int rows_per_batch, int krows, int M, int N,
+                 int batch, const float* mean_a, const float* mean_b, int splits, float* slabs, float* c, long ldc,
+                 long c_batch_stride, float scale, hipStream_t stream);
+
+int basd_colmean_parts(int rows);
+
+/* mean[z][c] = (1/rows) * sum_r X[z](r, c).   replaces `z.mean(dim=0)`  layer_selector.py:35, :91.
+ * `partial`: batch*parts*cols floats of scratch. */
+int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_per_batch, long batch_stride,
+                 int rows, int cols, int batch, int parts, float* partial, float* mean, hipStream_t stream);
+
+/* ---- one-sided Jacobi SVD / symmetric eigensolver ------------------------------------------ */
+
+int basd_jacobi_workspace_ints(int batch, int max_sweeps);
+
+/* In-place one-sided Jacobi on `batch` column-major matrices (rows_tot x n, leading dim rows_tot):
+ * right rotations orthogonalise the first rows_dot rows; colnorm receives the column norms.
+ * replaces the LAPACK calls behind torch.linalg.eigvalsh (layer_selector.py:16), torch.linalg.svd
+ * (:36, :92), torch.linalg.svdvals (:99) and torch.linalg.matrix_norm(ord="nuc") (relational.py:48).
+ * n_arr (nullable): per-matrix order for square problems.  flags: basd_jacobi_workspace_ints() ints. */
+int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot, int n, int batch,
+                         const int* n_arr, float* colnorm, int colnorm_stride, int max_sweeps, int* flags,
+                         int* sweeps_out, hipStream_t stream);
+
+/* Sort column norms descending; optionally emit the top-kmax normalised columns as rows
+ * (`Vt[:k]` of layer_selector.py:37, :97). */
+int basd_sort_extract(const float* W, long batch_stride, int rows, int rows_tot, int n, int batch,
+                      const float* colnorm, int colnorm_stride, float* vals_desc, float* vecs, int kmax,
+                      hipStream_t stream);
+
+/* ---- selector epilogues --------------------------------------------------------------------- */
+
+/* rank = min(#{eig > fp32(median_lower(eig) * factor)}, cap).  layer_selector.py:17-19, :74.
+ * factor = (1 + (D/M)**0.5)**2 evaluated by the HOST in float64 (layer_selector.py:11,18). */
+int basd_mp_rank(const float* vals_desc, int n, int batch, double factor, int cap, int* rank_out, float* thr_out,
+                 hipStream_t stream);
+
+/* d = sum(sw * acos(min(sigma, 1-eps))^2) / sum(sw) per (student layer, teacher layer) item.
+ * layer_selector.py:99-105. */
+int basd_grassmann_distance(const float* colnorm, int stride, const int* k_arr, const float* sw, int sw_stride,
+                            const int* sw_index, int items, float* d_out, float* theta_out, hipStream_t stream);
+
+int basd_sqrt_clamp(const float* in, float* out, long count, hipStream_t stream);
+
+/* ---- attention-weighted Procrustes loss ------------------------------------------------------ */
+
+/* Token weights from the layer-mixed attention.  relational.py:22-34 + layer_selector.py:112.
+ * attn_ptrs: device array of L pointers to (B, H, A, A) tensors sharing strides (sb, sh, sq, sk),
+ * A = n_a + has_cls.  atap*: weight interpolation n_a -> n_s; tap*: token interpolation n_t -> n_s
+ * (both NULL when the grids coincide). */
+int basd_token_weights(const void* const* attn_ptrs, int dtype, const float* mix, int L, long sb, long sh, long sq,
+                       long sk, int B, int H, int A, int has_cls, int n_a, int n_t, int n_s, const int* atap0,
+                       const int* atap1, const float* alam, const int* tap0, const int* tap1, const float* lam,
+                       float* omega, float* omega_t, float* raw_out, hipStream_t stream);
+
+/* Student half of relational.py:36-45 and the adjoint of combined.py:9-14:
+ * mu = sum_n w_n x_n, tr_s = sum_n w_n |x_n - mu|^2, A' = I_interp^T diag(w) (X - 1 mu^T). */
+int basd_student_project(const void* x, int dtype, long sb, long sn, int B, int n_s, int n_t, int D,
+                         const float* omega, const int* tap0, const int* tap1, const float* lam, const int* range0,
+                         const int* range1, float* mu, float* tr_s, float* a_prime, hipStream_t stream);
+
+/* Teacher half: soft layer mixing (layer_selector.py:110-111) + weighted centring (relational.py:37,39)
+ * on the teacher's own token grid.  tok_ptrs: device array of L pointers sharing strides. */
+int basd_teacher_center(const void* const* tok_ptrs, int dtype, const float* mix, int L, long sb, long sn, long sd,
+                        int B, int n_t, int D, const float* omega_t, float* mu, float* tc, hipStream_t stream);
+
+/* G[b] = P[b] P[b]^T accumulated in fp64 on v_mfma_f64_16x16x4_f64 (the bmm of relational.py:47,
+ * reduced to the teacher grid). */
+int basd_gram_f64(const float* p, long p_batch_stride, int n, int D, int batch, double* g, long g_batch_stride,
+                  hipStream_t stream);
+
+/* fp64 Cholesky of (possibly singular) PSD matrices; L full row-major. */
+int basd_chol_f64(const double* g, long g_batch_stride, int n, int batch, double* l, long l_batch_stride,
+                  hipStream_t stream);
+
+/* W[b] = [L_a^T L_b ; L_b]  (2n x n column-major fp32) -- the input of basd_jacobi_onesided. */
+int basd_stack_product(const double* la, const double* lb, long l_batch_stride, int n, int batch, float* w,
+                       long w_batch_stride, hipStream_t stream);
+
+/* Per sample: tr_t, nuclear norm (relational.py:48), loss_b = tr_s + tr_t - 2 nuc (relational.py:50),
+ * and K' = Y Sigma^+ Y^T for the backward (nullable). */
+int basd_procrustes_finalize(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
+                             const double* gb, long g_batch_stride, const float* omega, const int* tap0,
+                             const int* tap1, const float* lam, const float* tr_s, float* tr_t, float* nuc,
+                             float* loss, float* k_prime, hipStream_t stream);
+
+/* dX = (*scale_ptr * scale_const) * w_s * ((x_s - mu) - interp(K' A')[s]): autograd of relational.py:36-50
+ * with respect to the student tokens. */
+int basd_student_grad(const void* x, int dtype, long sb, long sn, int B, int n_s, int n_t, int D, const float* omega,
+                      const float* mu, const float* h, const int* tap0, const int* tap1, const float* lam,
+                      const float* scale_ptr, float scale_const, float* dx, hipStream_t stream);
+
+/* Stand-alone `_align_token_count` (combined.py:9-14): out (B, n_out, D) fp32 contiguous; and its adjoint. */
+int basd_resample_tokens(const void* x, int dtype, long sb, long sn, long sd, int B, int n_in, int n_out, int D,
+                         const int* tap0, const int* tap1, const float* lam, float* out, hipStream_t stream);
+int basd_resample_tokens_adjoint(const float* dy, int B, int n_in, int n_out, int D, const int* tap0,
+                                 const int* tap1, const float* lam, const int* range0, const int* range1, float* dx,
+                                 hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASD_HIP_H */

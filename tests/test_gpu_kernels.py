@@ -1,0 +1,151 @@
+"""Per-kernel numerics on a real MI355X, each against an fp64 torch reference of the same op."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+
+
+def test_gemm_nt_layouts(dev):
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(1)
+    B, N, K, Nout = 5, 49, 260, 96
+    x = torch.randn(B, N, K, generator=g).to(dev)
+    w = torch.randn(Nout, K, generator=g).to(dev)
+    ref = x.double().reshape(-1, K) @ w.double().T
+    assert _rel(ops.gemm_nt(x, w), ref) < 2e-6
+    full = torch.zeros(B, N + 1, K, device=dev)
+    full[:, 1:] = x
+    assert _rel(ops.gemm_nt(full[:, 1:], w), ref) < 2e-6              # CLS-sliced view
+    chan = x.transpose(1, 2).contiguous().transpose(1, 2)             # channel-major view
+    assert not chan.is_contiguous()
+    assert _rel(ops.gemm_nt(chan, w), ref) < 2e-6
+    assert _rel(ops.gemm_nt(x.bfloat16(), w), x.bfloat16().double().reshape(-1, K) @ w.double().T) < 2e-6
+    big = torch.randn(700, 1024, generator=g).to(dev)
+    wb = torch.randn(384, 1024, generator=g).to(dev)
+    assert _rel(ops.gemm_nt(big, wb, scale=0.5), 0.5 * big.double() @ wb.double().T) < 2e-6
+
+
+def test_gemm_tn_and_colmean(dev):
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(7, 197, 200, generator=g) + 1.5).to(dev)[:, 1:, :]   # strided rows
+    flat = x.double().reshape(-1, 200)
+    mean = ops.colmean(x)
+    assert _rel(mean, flat.mean(0)) < 1e-6
+    assert _rel(ops.gemm_tn(x, x, scale=1.0 / flat.shape[0]), flat.T @ flat / flat.shape[0]) < 2e-6
+    c = flat - flat.mean(0)
+    assert _rel(ops.gemm_tn(x, x, mean_a=mean, mean_b=mean), c.T @ c) < 5e-6
+    # batched, no split:  C[z] = A[z]^T B[z]
+    a = torch.randn(6, 49, 49, generator=g).to(dev)
+    b = torch.randn(6, 49, 130, generator=g).to(dev)
+    out = ops.gemm_tn(a[0], b[0], batch=6, a_batch_stride=49 * 49, b_batch_stride=49 * 130, krows=49, m_cols=49,
+                      n_cols=130, split=False)
+    assert _rel(out, a.double().transpose(1, 2) @ b.double()) < 2e-6
+
+
+@pytest.mark.parametrize("n,rows_dot,rows_tot", [(49, 49, 98), (50, 50, 100), (7, 7, 7), (96, 96, 192), (130, 130, 130)])
+def test_jacobi_lds_invariants(dev, n, rows_dot, rows_tot):
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(n)
+    batch = 5
+    w0 = torch.randn(batch, n, rows_tot, generator=g)
+    w0[:, :, :rows_dot] *= torch.logspace(0, -3, n).view(1, n, 1)       # spread the spectrum
+    W = w0.clone().to(dev)
+    sigma, sweeps = ops.jacobi_onesided(W, rows_dot, want_sweeps=True)
+    assert int(sweeps.max()) < ops.MAX_SWEEPS, "did not converge"
+    top0 = w0[:, :, :rows_dot].double()            # column c = w0[b, c, :]
+    top = W[:, :, :rows_dot].double().cpu()
+    sv = torch.linalg.svdvals(top0)
+    got = sigma.double().cpu().sort(dim=1, descending=True).values
+    assert ((got - sv).abs().max(dim=1).values / sv[:, 0]).max() < 3e-6
+    gram = top @ top.transpose(1, 2)                                    # columns orthogonal -> diagonal
+    off = gram - torch.diag_embed(torch.diagonal(gram, dim1=1, dim2=2))
+    nrm = torch.diagonal(gram, dim1=1, dim2=2).sqrt()
+    assert (off.abs() / (nrm.unsqueeze(2) * nrm.unsqueeze(1)).clamp_min(1e-30)).max() < 5e-6
+    if rows_tot > rows_dot:                                             # right-orthogonal invariants
+        bot0 = w0[:, :, rows_dot:].double()
+        bot = W[:, :, rows_dot:].double().cpu()
+        assert _rel(bot.transpose(1, 2) @ bot, bot0.transpose(1, 2) @ bot0) < 1e-5
+        assert _rel(top.transpose(1, 2) @ bot, top0.transpose(1, 2) @ bot0) < 1e-5
+
+
+def test_jacobi_per_matrix_order(dev):
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(3)
+    kmax = 40
+    ks = [40, 17, 1, 0, 33]
+    mats = torch.randn(len(ks), kmax, kmax, generator=g)
+    W = mats.clone().to(dev)
+    sigma = ops.jacobi_onesided(W, kmax, n_arr=torch.tensor(ks, dtype=torch.int32, device=dev)).cpu()
+    for i, k in enumerate(ks):
+        if k == 0:
+            continue
+        ref = torch.linalg.svdvals(mats[i, :k, :k].double())
+        got = sigma[i, :k].double().sort(descending=True).values
+        assert (got - ref).abs().max() / ref[0] < 3e-6
+
+
+@pytest.mark.parametrize("n", [384, 200])
+def test_sym_eig_block_path(dev, n):
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(3, 4 * n, n, generator=g)
+    x[:, :, :20] *= 6.0
+    G0 = (x.transpose(1, 2) @ x).to(dev)
+    vals, vecs, _, _ = ops.sym_eig(G0.clone(), kmax=24)
+    ref = torch.linalg.eigvalsh(G0.double().cpu()).flip(1)
+    assert ((vals.double().cpu() - ref).abs().max(dim=1).values / ref[:, 0]).max() < 3e-6
+    v = vecs.double().cpu()                                             # rows are eigenvectors
+    resid = G0.double().cpu() @ v.transpose(1, 2) - v.transpose(1, 2) * vals[:, :24].double().cpu().unsqueeze(1)
+    assert resid.norm(dim=1).max() / ref[:, 0].max() < 2e-5
+    eye = v @ v.transpose(1, 2)
+    assert (eye - torch.eye(24)).abs().max() < 2e-5
+
+
+def test_gram_chol_f64(dev):
+    from basd_amd import _lib, ops
+    g = torch.Generator().manual_seed(4)
+    for n, D in [(49, 384), (196, 96), (20, 36)]:
+        p = torch.randn(3, n, D, generator=g).to(dev)
+        p[2] = p[2] - p[2].mean(0, keepdim=True)      # exactly singular Gram
+        G = torch.empty(3, n, n, device=dev, dtype=torch.float64)
+        _lib.call("basd_gram_f64", p.data_ptr(), n * D, n, D, 3, G.data_ptr(), n * n, ops._stream())
+        ref = p.double() @ p.double().transpose(1, 2)
+        assert _rel(G, ref) < 1e-14
+        L = torch.empty_like(G)
+        _lib.call("basd_chol_f64", G.data_ptr(), n * n, n, 3, L.data_ptr(), n * n, ops._stream())
+        assert torch.equal(L.triu(1), torch.zeros_like(L))
+        if n <= D:
+            assert _rel(L @ L.transpose(1, 2), ref) < 1e-12
+        else:
+            assert _rel(L @ L.transpose(1, 2), ref) < 1e-9   # rank-deficient: zero pivots
+
+
+def test_resample_matches_interpolate(dev):
+    from basd_amd.losses import _align_token_count
+    g = torch.Generator().manual_seed(5)
+    for n_in, n_out in [(49, 196), (256, 196), (144, 576), (1, 64)]:
+        x = torch.randn(2, n_in, 24, generator=g).to(dev).requires_grad_(True)
+        y = _align_token_count(x, n_out)
+        ref_in = x.detach().clone().requires_grad_(True)
+        ref = torch.nn.functional.interpolate(ref_in.transpose(1, 2), size=n_out, mode="linear",
+                                              align_corners=False).transpose(1, 2)
+        assert (y - ref).abs().max() < 5e-7
+        gy = torch.randn(y.shape, generator=g).to(dev)
+        y.backward(gy)
+        ref.backward(gy)
+        assert (x.grad - ref_in.grad).abs().max() < 2e-6

@@ -1,0 +1,205 @@
+"""Parity of the HIP path with the CPU oracle and with the golden fixtures generated from the
+reference (tests/golden).  Tolerances: loss values 1e-4 relative (north star), ranks exact."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import make_goldens_shapes as S
+from basd_amd import synth
+from oracle import basd_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _module(shape, ls):
+    from basd_amd.losses import BASDLoss
+    torch.manual_seed(42)
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=ls)
+    return BASDLoss(crit, shape.d_s, shape.d_t, shape.depth, shape.n_s,
+                    config=SimpleNamespace(num_extraction_points=shape.points),
+                    teacher_has_cls_token=shape.has_cls).to(DEV)
+
+
+def test_mp_rank_golden(golden):
+    from basd_amd.losses import marchenko_pastur_rank
+    g = golden("mp_rank.npz")
+    cases = [("m32_d192", 32, 192, 6), ("m128_d192", 128, 192, 10), ("m1000_d384", 1000, 384, 24),
+             ("m12544_d384", 12544, 384, 48)]
+    for i, (tag, m, d, r) in enumerate(cases):
+        gen = torch.Generator().manual_seed(100 + i)
+        x = synth.structured(gen, 1, m, d, r)[0]
+        assert marchenko_pastur_rank(x.to(DEV)) == int(g[f"{tag}_rank"]), tag
+    gen = torch.Generator().manual_seed(200)
+    noise = torch.randn(2000, 128, generator=gen)
+    assert marchenko_pastur_rank(noise.to(DEV)) == int(g["noise_rank"])
+
+
+def test_subspace_golden(golden):
+    from basd_amd.losses import _grassmann_subspace
+    g = golden("subspace.npz")
+    for i in range(3):
+        m, d, r, k = [int(v) for v in g[f"c{i}_shape"]]
+        gen = torch.Generator().manual_seed(300 + i)
+        z = synth.structured(gen, 1, m, d, r)[0] + 0.7
+        basis, s = _grassmann_subspace(z.to(DEV), k=k)
+        assert list(basis.shape) == list(g[f"c{i}_basis_shape"])
+        if k:
+            proj = (basis @ basis.T).cpu().numpy()
+            assert np.abs(proj - g[f"c{i}_proj"]).max() < 5e-4      # subspace projector (sign/rotation free)
+            np.testing.assert_allclose(s.cpu().numpy(), g[f"c{i}_svals"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["cls_same", "cls_interp", "nocls_uniform", "nocls_attn"])
+def test_relational_golden(golden, tag):
+    """geometric_relational_loss on the reference's own inputs: value, per-sample terms, student grad."""
+    from basd_amd import ops
+    from basd_amd.losses import geometric_relational_loss
+    g = golden("relational.npz")
+    cls = bool(g[f"{tag}_meta"][6])
+    s = T(g[f"{tag}_s"]).to(DEV).requires_grad_(True)
+    t = T(g[f"{tag}_t"]).to(DEV)
+    attn = T(g[f"{tag}_attn"]).to(DEV)
+    loss = geometric_relational_loss(s, t, attn, has_cls_token=cls)
+    np.testing.assert_allclose(loss.item(), g[f"{tag}_loss"], rtol=1e-4)
+    pc = ops.procrustes_forward([s.detach()], [t], [attn], torch.ones(1, 1, device=DEV), cls, need_backward=False)
+    np.testing.assert_allclose(pc.loss_b[0].cpu().numpy(), g[f"{tag}_per_sample"], rtol=1e-4)
+    loss.backward()
+    ref = g[f"{tag}_grad_s"]
+    err = np.linalg.norm(s.grad.cpu().numpy() - ref) / np.linalg.norm(ref)
+    assert err < 1e-4, (tag, err)
+
+
+@pytest.mark.parametrize("n_s,n_t,d_s,d_t,cls", [(196, 49, 384, 2048, False), (64, 64, 192, 256, True),
+                                                  (36, 9, 64, 160, False), (64, 1, 192, 512, False)])
+def test_procrustes_terms_vs_oracle(n_s, n_t, d_s, d_t, cls):
+    """tr_s, tr_t, nuc per sample against the oracle's LAPACK path, including the interpolated grids."""
+    from basd_amd import ops
+    gen = torch.Generator().manual_seed(n_s * 7 + n_t)
+    B = 6
+    s = synth.structured(gen, B, n_s, d_s, 8) + 0.5
+    t = synth.structured(gen, B, n_t, d_t, 6) - 0.25
+    a = n_t + (1 if cls else 0)
+    attn = torch.softmax(torch.randn(B, 3, a, a, generator=gen), dim=-1)
+    w = O.token_weights(attn, cls, n_s)
+    tr_s, tr_t, nuc = O.procrustes_terms(s, O.resample_tokens(t, n_s), w)
+    pc = ops.procrustes_forward([s.to(DEV)], [t.to(DEV)], [attn.to(DEV)], torch.ones(1, 1, device=DEV), cls,
+                                need_backward=False, want_sweeps=True)
+    assert int(pc.sweeps.max()) < ops.MAX_SWEEPS
+    np.testing.assert_allclose(pc.omega[0].cpu().numpy(), w.numpy(), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(pc.tr_s[0].cpu().numpy(), tr_s.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(pc.tr_t[0].cpu().numpy(), tr_t.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pc.nuc[0].cpu().numpy(), nuc.numpy(), rtol=2e-5, atol=1e-5)
+    ref_loss = (tr_s + tr_t - 2 * nuc).numpy()
+    np.testing.assert_allclose(pc.loss_b[0].cpu().numpy(), ref_loss, rtol=1e-4)
+
+
+def test_procrustes_exactly_low_rank_inputs():
+    """Rank-5 student x rank-7 teacher: the fp64 Gram/Cholesky front end keeps LAPACK-level accuracy
+    where an fp32 Gram route loses three digits."""
+    from basd_amd import ops
+    gen = torch.Generator().manual_seed(77)
+    B, n, d_s, d_t = 4, 64, 192, 256
+    s = torch.randn(B, n, 5, generator=gen) @ torch.randn(5, d_s, generator=gen)
+    t = torch.randn(B, n, 7, generator=gen) @ torch.randn(7, d_t, generator=gen)
+    attn = torch.ones(B, 1, n, n) / n
+    w = O.token_weights(attn, False, n)
+    tr_s, tr_t, nuc = O.procrustes_terms(s.double(), t.double(), w.double())
+    nuc64 = torch.linalg.svdvals(torch.bmm((w.unsqueeze(-1).sqrt() * (s - (w.unsqueeze(-1) * s).sum(1, keepdim=True))).double().transpose(1, 2),
+                                           (w.unsqueeze(-1).sqrt() * (t - (w.unsqueeze(-1) * t).sum(1, keepdim=True))).double())).sum(-1)
+    pc = ops.procrustes_forward([s.to(DEV)], [t.to(DEV)], [attn.to(DEV)], torch.ones(1, 1, device=DEV), False,
+                                need_backward=False)
+    np.testing.assert_allclose(pc.nuc[0].cpu().numpy(), nuc64.numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["cnn"])
+def test_full_small_golden(golden, tag):
+    g = golden("full_small.npz")
+    shape, seed = S.SMALL[tag]
+    mod = _module(shape, 0.01)
+    inp = synth.make_inputs(shape, seed, device=DEV)
+    leaves = {k: v.requires_grad_(True) for k, v in inp.student.items()}
+    logits = inp.logits.requires_grad_(True)
+    loss = mod(logits, inp.targets, leaves, inp.teacher, inp.attn)
+    assert mod.token_layers == list(g[f"{tag}_token_layers"])
+    assert [mod.layer_selector.subspace_ranks[k] for k in sorted(inp.teacher)] == list(g[f"{tag}_ranks"])
+    np.testing.assert_allclose(loss.item(), g[f"{tag}_loss"], rtol=1e-4)
+    loss.backward()
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), g[f"{tag}_grad_logits"], rtol=1e-4, atol=1e-8)
+    for l in mod.token_layers:
+        ref = g[f"{tag}_grad_student_{l}"]
+        err = np.linalg.norm(leaves[l].grad.cpu().numpy() - ref) / np.linalg.norm(ref)
+        assert err < 1e-4, (l, err)
+    np.testing.assert_array_equal(mod.layer_selector.log_temperatures.grad.cpu().numpy(),
+                                  g[f"{tag}_grad_log_temperatures"])
+
+
+@pytest.mark.parametrize("tag", ["vit", "vit_same"])
+def test_full_small_golden_multilayer_forward(golden, tag):
+    """Multi-layer (ViT) teachers: ranks, distances, mixing weights and the loss value (no grad)."""
+    g = golden("full_small.npz")
+    shape, seed = S.SMALL[tag]
+    mod = _module(shape, 0.01)
+    inp = synth.make_inputs(shape, seed, device=DEV)
+    with torch.no_grad():
+        loss = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
+    assert [mod.layer_selector.subspace_ranks[k] for k in sorted(inp.teacher)] == list(g[f"{tag}_ranks"])
+    np.testing.assert_allclose(mod.last_components["mix"].cpu().numpy(), g[f"{tag}_mix_weights"], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(loss.item(), g[f"{tag}_loss"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("name,seed,batch,ls,strided", [
+    ("cfg1", 1234, None, 0.01, False), ("cfg2", 1234, 8, 0.001, True), ("cfg2", 1235, 8, 0.001, False),
+    ("cfg5", 1234, 4, 0.001, True)])
+def test_baseline_scalars(golden, name, seed, batch, ls, strided):
+    g = golden("baseline_scalars.npz")
+    shape = synth.CONFIGS[name]
+    tag = f"{name}_s{seed}_b{batch or shape.batch}"
+    mod = _module(shape, ls)
+    inp = synth.make_inputs(shape, seed, batch=batch, device=DEV, strided=strided)
+    leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
+    loss = mod(inp.logits, inp.targets, leaves, inp.teacher, inp.attn)
+    assert [mod.layer_selector.subspace_ranks[k] for k in sorted(inp.teacher)] == list(g[f"{tag}_ranks"])
+    np.testing.assert_allclose(loss.item(), g[f"{tag}_loss"], rtol=1e-4)
+    loss.backward()
+    norms = np.array([leaves[l].grad.double().norm().item() for l in mod.token_layers])
+    np.testing.assert_allclose(norms, g[f"{tag}_grad_student_norms"], rtol=1e-3)
+
+
+def test_cfg4_forward_scalar(golden):
+    g = golden("baseline_scalars.npz")
+    shape = synth.CONFIGS["cfg4"]
+    mod = _module(shape, 0.001)
+    inp = synth.make_inputs(shape, 1234, batch=4, device=DEV, strided=True)
+    with torch.no_grad():
+        loss = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
+    assert [mod.layer_selector.subspace_ranks[k] for k in sorted(inp.teacher)] == list(g["cfg4_s1234_b4_ranks"])
+    np.testing.assert_allclose(loss.item(), g["cfg4_s1234_b4_loss"], rtol=1e-4)
+
+
+def test_cfg2_full_size(golden):
+    """BASELINE.json configs[1] at full size (B=256): golden loss from the reference's CPU run."""
+    g = golden("baseline_scalars.npz")
+    shape = synth.CONFIGS["cfg2"]
+    mod = _module(shape, 0.001)
+    inp = synth.make_inputs(shape, 1234, device=DEV, strided=True)
+    leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
+    loss = mod(inp.logits, inp.targets, leaves, inp.teacher, inp.attn)
+    assert list(mod.layer_selector.subspace_ranks.values()) == list(g["cfg2_s1234_b256_ranks"])
+    np.testing.assert_allclose(loss.item(), g["cfg2_s1234_b256_loss"], rtol=1e-4)
+    loss.backward()
+    norms = np.array([leaves[l].grad.double().norm().item() for l in mod.token_layers])
+    np.testing.assert_allclose(norms, g["cfg2_s1234_b256_grad_student_norms"], rtol=1e-3)
+    # size-independent properties: per-sample Procrustes loss is non-negative; total = harmonic mean
+    comp = mod.last_components
+    ce, geo = comp["ce"].item(), comp["geo_layers"].mean().item()
+    assert abs(loss.item() - 2 * ce * geo / (ce + geo)) < 1e-4 * loss.item()

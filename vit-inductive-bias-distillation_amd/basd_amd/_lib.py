@@ -1,0 +1,78 @@
+"""ctypes binding of ``libbasd_hip.so`` (C ABI declared in ``include/basd_hip.h``).
+
+There is deliberately no CPU fallback: if the library is missing, or a call
+returns a non-zero status, a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbasd_hip.so")
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+
+# name -> argtypes (return type is always int)
+SIGNATURES = {
+    "basd_gemm_nt": [vp, i32, i64, i64, i64, i32, i64, vp, i64, i64, i32, i32, i32, i32, vp, i64, i64, f32, vp],
+    "basd_gemm_tn_splits": [i32],
+    "basd_gemm_tn": [vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp,
+                     vp, i64, i64, f32, vp],
+    "basd_colmean_parts": [i32],
+    "basd_colmean": [vp, i32, i64, i64, i64, i32, i64, i32, i32, i32, i32, vp, vp, vp],
+    "basd_jacobi_workspace_ints": [i32, i32],
+    "basd_jacobi_onesided": [vp, i64, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp],
+    "basd_sort_extract": [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
+    "basd_mp_rank": [vp, i32, i32, f64, i32, vp, vp, vp],
+    "basd_grassmann_distance": [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp],
+    "basd_sqrt_clamp": [vp, vp, i64, vp],
+    "basd_token_weights": [vp, i32, vp, i32, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp,
+                           vp, vp, vp, vp, vp, vp],
+    "basd_student_project": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "basd_teacher_center": [vp, i32, vp, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp],
+    "basd_gram_f64": [vp, i64, i32, i32, i32, vp, i64, vp],
+    "basd_chol_f64": [vp, i64, i32, i32, vp, i64, vp],
+    "basd_stack_product": [vp, vp, i64, i32, i32, vp, i64, vp],
+    "basd_procrustes_finalize": [vp, i64, vp, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "basd_resample_tokens": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "basd_resample_tokens_adjoint": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "basd_student_grad": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp],
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} not found: build it with `make -C vit-inductive-bias-distillation_amd/csrc` "
+                    "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+            lib = C.CDLL(LIB_PATH)
+            for name, argtypes in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.argtypes = argtypes
+                fn.restype = C.c_int
+            _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    """Call an entry point that reports a status; non-zero becomes RuntimeError."""
+    status = getattr(load(), name)(*args)
+    if status != 0:
+        kind = "invalid argument / unsupported shape" if status < 0 else "HIP error"
+        raise RuntimeError(f"{name} failed with status {status} ({kind})")
+
+
+def query(name: str, *args) -> int:
+    """Call a pure host-side sizing helper (returns a count, not a status)."""
+    return int(getattr(load(), name)(*args))

@@ -1,0 +1,348 @@
+"""The reference's loss API (``src/losses``) over the MI355X kernels.
+
+Same class / function names, constructor arguments, state_dict keys, public
+attributes and error behaviour as the reference modules
+(``src/losses/combined.py``, ``layer_selector.py``, ``relational.py``); the
+arithmetic runs in ``libbasd_hip.so``.  Importing this module does not need a
+GPU; calling anything numerical without the HIP library or with CPU tensors
+raises ``RuntimeError`` (no fallback path exists).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+__all__ = [
+    "BASDLoss", "GrassmannianLayerSelector", "geometric_relational_loss", "marchenko_pastur_rank",
+    "_grassmann_subspace", "_align_token_count",
+]
+
+
+# --------------------------------------------------------------------------- #
+# reference src/losses/layer_selector.py:8-20
+# --------------------------------------------------------------------------- #
+def _uncentred_gram(features: torch.Tensor) -> torch.Tensor:
+    """Gram on the smaller side, scaled by 1/M, not centred (layer_selector.py:12-15)."""
+    M, D = features.shape
+    if M >= D:
+        return ops.gemm_tn(features, features, scale=1.0 / M)
+    x = features if features.stride(1) == 1 and features.dtype == torch.float32 else features.float().contiguous()
+    return ops.gemm_nt(x, x, scale=1.0 / M)
+
+
+@torch.no_grad()
+def marchenko_pastur_rank(features: torch.Tensor) -> int:
+    features = ops.as_supported(features)
+    M, D = features.shape
+    gram = _uncentred_gram(features).unsqueeze(0)
+    vals, _, _, _ = ops.sym_eig(gram)
+    rank = ops.mp_rank_device(vals, M, D, cap=1 << 30)
+    return int(rank.item())
+
+
+# --------------------------------------------------------------------------- #
+# reference src/losses/layer_selector.py:23-37
+# --------------------------------------------------------------------------- #
+def _grassmann_subspace(z_flat: torch.Tensor, *, k: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """Top-k PCA subspace: (basis (D, k), singular values (k,)) of the column-centred input."""
+    with torch.no_grad():
+        z = ops.as_supported(z_flat)
+        mean = ops.colmean(z)
+        gram = ops.gemm_tn(z, z, mean_a=mean, mean_b=mean).unsqueeze(0)
+        vals, vecs, _, _ = ops.sym_eig(gram, kmax=max(k, 1))
+        k_eff = min(k, min(z.shape))
+        basis = vecs[0, :k_eff].T.contiguous()
+        svals = ops.sqrt_clamp(vals[0, :k_eff]) if k_eff > 0 else vals[0, :0]
+    return basis, svals
+
+
+# --------------------------------------------------------------------------- #
+# reference src/losses/combined.py:9-14
+# --------------------------------------------------------------------------- #
+class _Resample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens: torch.Tensor, target_n: int):
+        x = ops.as_supported(tokens)
+        B, n_in, D = x.shape
+        tp = ops.taps(n_in, target_n, x.device)
+        out = torch.empty((B, target_n, D), device=x.device, dtype=torch.float32)
+        ops._lib.call("basd_resample_tokens", x.data_ptr(), ops._dtype_code(x), x.stride(0), x.stride(1), x.stride(2),
+                      B, n_in, target_n, D, tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr(),
+                      out.data_ptr(), ops._stream())
+        ctx.shape = (B, n_in, D, target_n)
+        ctx.in_dtype = tokens.dtype
+        return out.to(tokens.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        B, n_in, D, n_out = ctx.shape
+        g = grad_out.float().contiguous()
+        tp = ops.taps(n_in, n_out, g.device)
+        dx = torch.empty((B, n_in, D), device=g.device, dtype=torch.float32)
+        ops._lib.call("basd_resample_tokens_adjoint", g.data_ptr(), B, n_in, n_out, D, tp.tap0.data_ptr(),
+                      tp.tap1.data_ptr(), tp.lam.data_ptr(), tp.range0.data_ptr(), tp.range1.data_ptr(),
+                      dx.data_ptr(), ops._stream())
+        return dx.to(ctx.in_dtype), None
+
+
+def _align_token_count(tokens: torch.Tensor, target_n: int) -> torch.Tensor:
+    if tokens.shape[1] == target_n:
+        return tokens
+    return _Resample.apply(tokens, target_n)
+
+
+# --------------------------------------------------------------------------- #
+# Procrustes loss over all extraction layers (autograd boundary)
+# --------------------------------------------------------------------------- #
+class _ProcrustesLayers(torch.autograd.Function):
+    """(mix (E, L), has_cls, teachers, attns, *students) -> per-layer loss (E,)."""
+
+    @staticmethod
+    def forward(ctx, mix, has_cls, teachers, attns, *students):
+        need_bwd = any(s.requires_grad for s in students)
+        pc = ops.procrustes_forward(list(students), teachers, attns, mix.detach(), has_cls, need_backward=need_bwd)
+        ctx.pc = pc
+        ctx.n_students = len(students)
+        ctx.save_for_backward(*students)
+        ctx.mix_needs_grad = mix.requires_grad and mix.shape[1] > 1
+        ctx.mix_shape = tuple(mix.shape)
+        return pc.loss_b.mean(dim=1)
+
+    @staticmethod
+    def backward(ctx, grad_layers):
+        students = ctx.saved_tensors
+        if ctx.mix_needs_grad:
+            raise NotImplementedError(
+                "gradient through the layer-mixing weights (multi-layer teachers) is not implemented yet")
+        # a single teacher layer: softmax over one logit is constant, so d loss / d mix is exactly 0
+        g_mix = torch.zeros(ctx.mix_shape, device=grad_layers.device) if ctx.needs_input_grad[0] else None
+        if ctx.pc.k_prime is None:
+            return (g_mix, None, None, None) + (None,) * ctx.n_students
+        grads = ops.procrustes_student_grads(list(students), ctx.pc, grad_layers)
+        grads = [g.to(s.dtype) if ctx.needs_input_grad[4 + i] else None
+                 for i, (g, s) in enumerate(zip(grads, students))]
+        return (g_mix, None, None, None, *grads)
+
+
+# --------------------------------------------------------------------------- #
+# reference src/losses/relational.py:5-50
+# --------------------------------------------------------------------------- #
+def geometric_relational_loss(
+    student_tokens: torch.Tensor,
+    teacher_tokens: torch.Tensor,
+    teacher_attn: torch.Tensor,
+    *,
+    has_cls_token: bool,
+) -> torch.Tensor:
+    """Attention-weighted Procrustes loss between (B, N_s, D_s) student tokens and (B, N_s, D_t)
+    teacher tokens already on the student grid.  Differentiable w.r.t. the student tokens."""
+    if teacher_tokens.shape[1] != student_tokens.shape[1]:
+        raise RuntimeError("teacher_tokens must already be aligned to the student token count")
+    if teacher_tokens.requires_grad or teacher_attn.requires_grad:
+        raise NotImplementedError("gradients w.r.t. teacher tokens / attention are not implemented yet")
+    mix = torch.ones((1, 1), device=student_tokens.device, dtype=torch.float32)
+    return _ProcrustesLayers.apply(mix, bool(has_cls_token), [teacher_tokens], [teacher_attn], student_tokens)[0]
+
+
+# --------------------------------------------------------------------------- #
+# reference src/losses/layer_selector.py:40-152
+# --------------------------------------------------------------------------- #
+class GrassmannianLayerSelector(nn.Module):
+    def __init__(self, num_extraction_points: int, student_dim: int, teacher_dim: int):
+        super().__init__()
+        self.student_dim = student_dim
+        self.subspace_ranks: dict[int, int] = {}
+
+        # Same global-RNG consumption order as the reference (proj_s, then proj_t), on CPU.
+        proj_s = torch.empty(student_dim, student_dim)
+        proj_t = torch.empty(student_dim, teacher_dim)
+        nn.init.orthogonal_(proj_s)
+        nn.init.orthogonal_(proj_t)
+        self.register_buffer("proj_s", proj_s)
+        self.register_buffer("proj_t", proj_t)
+        self.log_temperatures = nn.Parameter(
+            torch.full((num_extraction_points,), math.log(math.exp(1.0) - 1)))
+
+    @property
+    def temperatures(self) -> torch.Tensor:
+        return F.softplus(self.log_temperatures)
+
+    # ---- teacher side: ranks + subspaces -------------------------------------------------
+    @torch.no_grad()
+    def _teacher_spectra(self, teachers: list[torch.Tensor]):
+        """Per teacher layer: projected tokens -> uncentred Gram eigenvalues (for the MP rank) and the
+        centred Gram's eigen-decomposition (for the subspace).  Returns device ranks + solver state."""
+        d_s = self.student_dim
+        L = len(teachers)
+        B, n_t, d_t = teachers[0].shape
+        M = B * n_t
+        proj_t = self.proj_t.float().contiguous()
+        n_u = d_s if M >= d_s else M
+        g_u = torch.empty((L, n_u, n_u), device=proj_t.device, dtype=torch.float32)
+        g_c = torch.empty((L, d_s, d_s), device=proj_t.device, dtype=torch.float32)
+        for l, t in enumerate(teachers):
+            z = ops.gemm_nt(ops.as_supported(t), proj_t)              # (M, d_s)  layer_selector.py:72 / :135
+            g_u[l] = _uncentred_gram(z)                               # layer_selector.py:12-15
+            mean = ops.colmean(z)
+            g_c[l] = ops.gemm_tn(z, z, mean_a=mean, mean_b=mean)      # centred z^T z  (:35)
+        vals_u, _, _, _ = ops.sym_eig(g_u)
+        ranks_dev = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
+        colnorm_c = ops.jacobi_onesided(g_c, d_s)
+        return ranks_dev, g_c, colnorm_c
+
+    @torch.no_grad()
+    def _estimate_ranks(self, all_teacher_tokens: dict[int, torch.Tensor]) -> None:
+        keys = list(all_teacher_tokens.keys())
+        teachers = ops._check_common_layout([ops.as_supported(all_teacher_tokens[k]) for k in keys],
+                                            "teacher token tensors")
+        ranks_dev, _, _ = self._teacher_spectra(teachers)
+        for k, r in zip(keys, ranks_dev.tolist()):
+            self.subspace_ranks[k] = int(r)
+
+    # ---- distances + mixing weights ------------------------------------------------------
+    def _distances(self, students: list[torch.Tensor], keys: list[int], teachers: list[torch.Tensor]) -> torch.Tensor:
+        """d_grass_sq (E, L) (layer_selector.py:86-105).  Refreshes ``subspace_ranks``."""
+        with torch.no_grad():
+            d_s = self.student_dim
+            E, L = len(students), len(teachers)
+            dev = students[0].device
+            ranks_dev, g_c, colnorm_c = self._teacher_spectra(teachers)
+            # student side is queued before the one host read-back of the step
+            s_gram = torch.empty((E, d_s, d_s), device=dev, dtype=torch.float32)
+            for e, x in enumerate(students):
+                x = ops.as_supported(x)
+                mean = ops.colmean(x)
+                # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
+                # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
+                s_gram[e] = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
+            s_colnorm = ops.jacobi_onesided(s_gram, d_s)
+            ranks = [int(r) for r in ranks_dev.tolist()]               # the step's single D2H sync
+            for k, r in zip(keys, ranks):
+                self.subspace_ranks[k] = r
+            if min(ranks) == 0:
+                # reference: 0/0 distance -> NaN weights -> NaN tokens -> torch.linalg.svd raises
+                raise torch.linalg.LinAlgError(
+                    "linalg.svd: The algorithm failed to converge because the input matrix contained "
+                    "non-finite values (a teacher layer has Marchenko-Pastur rank 0).")
+            kmax = max(ranks)
+            vals_c, u_t = ops.sort_extract(g_c, colnorm_c, kmax)       # (L, d_s), (L, kmax, d_s) rows = basis^T
+            sw = ops.sqrt_clamp(vals_c[:, :kmax])                      # singular values S[:k]   (:36-37)
+            _, v_s = ops.sort_extract(s_gram, s_colnorm, kmax)         # (E, kmax, d_s) rows = Vt_s[:kmax]
+            proj_s_t = self.proj_s.float().t().contiguous()
+            u_rot = ops.gemm_nt(u_t.view(L * kmax, d_s), proj_s_t).view(L, kmax, d_s)   # rows: (proj_s^T u)^T
+            cos = torch.empty((E, L, kmax, kmax), device=dev, dtype=torch.float32)
+            for e in range(E):
+                ops.gemm_nt(v_s[e], u_rot[0], out=cos[e], batch=L, a_batch_stride=0, b_batch_stride=kmax * d_s,
+                            rows=kmax, n_cols=kmax)                    # Vt_s[:k] @ U_t   (:99)
+            k_arr = ranks_dev.repeat(E).contiguous()
+            sigma = ops.jacobi_onesided(cos.view(E * L, kmax, kmax), kmax, n_arr=k_arr)
+            sw_index = torch.arange(L, device=dev, dtype=torch.int32).repeat(E).contiguous()
+            d = ops.grassmann_distance(sigma, k_arr, sw, sw_index)     # (:100-105)
+        return d.view(E, L)
+
+    def mixing_weights(self, students: list[torch.Tensor], keys: list[int],
+                       teachers: list[torch.Tensor]) -> torch.Tensor:
+        """softmax(-d / tau) per extraction layer -> (E, L)   (layer_selector.py:107-108)."""
+        d = self._distances(students, keys, teachers)
+        tau = self.temperatures.float()
+        return torch.softmax(-d / tau.unsqueeze(1), dim=1)
+
+    def forward(
+        self,
+        student_tokens_per_layer: dict[int, torch.Tensor],
+        all_teacher_tokens: dict[int, torch.Tensor],
+        all_teacher_attns: dict[int, torch.Tensor],
+        extraction_indices: list[int],
+    ) -> tuple[dict[int, torch.Tensor], dict[int, torch.Tensor]]:
+        """API-parity entry point: returns the materialised mixed teacher tokens / attention maps.
+        (``BASDLoss`` does not call this -- it feeds the mixing weights straight to the fused loss.)"""
+        keys = sorted(all_teacher_tokens.keys())
+        teachers = ops._check_common_layout([ops.as_supported(all_teacher_tokens[k]) for k in keys],
+                                            "teacher token tensors")
+        students = [student_tokens_per_layer[s] for s in extraction_indices]
+        if len(keys) > 1 and torch.is_grad_enabled() and any(s.requires_grad for s in students):
+            raise NotImplementedError("selector backward for multi-layer teachers is not implemented yet")
+        mix = self.mixing_weights(students, keys, teachers)
+        tok_stack = torch.stack([all_teacher_tokens[k] for k in keys])
+        att_stack = torch.stack([all_teacher_attns[k] for k in keys])
+        mixed_t, mixed_a = {}, {}
+        for i, s_layer in enumerate(extraction_indices):
+            w = mix[i].to(tok_stack.dtype)
+            mixed_t[s_layer] = (w.view(-1, 1, 1, 1) * tok_stack).sum(dim=0)
+            mixed_a[s_layer] = (w.view(-1, 1, 1, 1, 1) * att_stack).sum(dim=0)
+        return mixed_t, mixed_a
+
+
+# --------------------------------------------------------------------------- #
+# reference src/losses/combined.py:17-85
+# --------------------------------------------------------------------------- #
+class BASDLoss(nn.Module):
+    def __init__(
+        self,
+        base_criterion: nn.Module,
+        student_dim: int,
+        teacher_dim: int,
+        student_depth: int,
+        num_student_tokens: int,
+        *,
+        config,
+        teacher_has_cls_token: bool,
+    ):
+        super().__init__()
+        self.base_criterion = base_criterion
+        self.teacher_has_cls_token = teacher_has_cls_token
+        self.num_student_tokens = num_student_tokens
+
+        if config.num_extraction_points == 1:
+            self.token_layers = [student_depth - 1]
+        else:
+            self.token_layers = [
+                round(i * (student_depth - 1) / (config.num_extraction_points - 1))
+                for i in range(config.num_extraction_points)
+            ]
+        self.layer_selector = GrassmannianLayerSelector(
+            num_extraction_points=len(self.token_layers),
+            student_dim=student_dim,
+            teacher_dim=teacher_dim,
+        )
+        self.last_components: dict[str, torch.Tensor] = {}
+
+    @torch.compiler.disable
+    def forward(
+        self,
+        student_output: torch.Tensor,
+        targets: torch.Tensor,
+        student_intermediates: dict[int, torch.Tensor],
+        all_teacher_tokens: dict[int, torch.Tensor],
+        all_teacher_attns: dict[int, torch.Tensor],
+    ) -> torch.Tensor:
+        ce_loss = self.base_criterion(student_output, targets)
+
+        keys = sorted(all_teacher_tokens.keys())
+        students = [student_intermediates[l] for l in self.token_layers]
+        for s in students:
+            if s.shape[1] != self.num_student_tokens:
+                raise RuntimeError(
+                    f"student tokens have {s.shape[1]} tokens, expected num_student_tokens={self.num_student_tokens}")
+        teachers = ops._check_common_layout([ops.as_supported(all_teacher_tokens[k]) for k in keys],
+                                            "teacher token tensors")
+        attns = [all_teacher_attns[k] for k in keys]
+        if len(keys) > 1 and torch.is_grad_enabled() and any(s.requires_grad for s in students):
+            raise NotImplementedError("selector backward for multi-layer teachers is not implemented yet")
+
+        mix = self.layer_selector.mixing_weights(students, keys, teachers)
+        geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
+        geo_loss = geo_layers.mean()
+
+        vals = [ce_loss, geo_loss]
+        # UW-SO weighting: w_i = (1/L_i) / sum_j (1/L_j), weights detached   (combined.py:78-85)
+        eps = torch.finfo(vals[0].dtype).eps
+        inv = torch.stack([1.0 / v.detach().clamp(min=eps) for v in vals])
+        w = inv / inv.sum()
+        self.last_components = {"ce": ce_loss.detach(), "geo_layers": geo_layers.detach(), "mix": mix.detach()}
+        return sum(w[i] * vals[i] for i in range(len(vals)))

@@ -1,0 +1,361 @@
+"""Host-side orchestration of the HIP kernels (thin wrappers over the C ABI).
+
+PyTorch is used here for device memory (the caching allocator hands out scratch
+without synchronising), the current HIP stream, and autograd bookkeeping; all
+arithmetic on the path runs in ``libbasd_hip.so``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from functools import lru_cache
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+MAX_SWEEPS = 30
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def as_supported(t: torch.Tensor) -> torch.Tensor:
+    """fp32 and bf16 are consumed in place; anything else is widened to fp32."""
+    if t.dtype in (torch.float32, torch.bfloat16):
+        return t
+    return t.float()
+
+
+def _require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("basd_amd kernels need CUDA/HIP tensors (there is no CPU fallback)")
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _tok3(x: torch.Tensor) -> tuple[int, int, int, int, int, int]:
+    """(ptr, dtype, sb, sn, sd, rows_per_batch) of a (B, N, D) or (M, D) view."""
+    if x.dim() == 2:
+        return x.data_ptr(), _dtype_code(x), 0, x.stride(0), x.stride(1), 1 << 30
+    assert x.dim() == 3
+    return x.data_ptr(), _dtype_code(x), x.stride(0), x.stride(1), x.stride(2), x.shape[1]
+
+
+# --------------------------------------------------------------------------- #
+# dense contractions
+# --------------------------------------------------------------------------- #
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, scale: float = 1.0, out: torch.Tensor | None = None,
+            a_batch_stride: int = 0, b_batch_stride: int = 0, batch: int = 1, rows: int | None = None,
+            n_cols: int | None = None) -> torch.Tensor:
+    """C = scale * A @ B.T.  A: (B,N,K) or (M,K) view in fp32/bf16; B: (N,K) fp32 row-major.
+    With batch > 1, element z uses a/b advanced by the given batch strides."""
+    _require_cuda(a, b)
+    ptr, dt, sb, sn, sd, rpb = _tok3(a)
+    M = rows if rows is not None else (a.shape[0] * a.shape[1] if a.dim() == 3 else a.shape[0])
+    K = a.shape[-1]
+    N = n_cols if n_cols is not None else b.shape[-2]
+    assert b.dtype == torch.float32 and b.stride(-1) == 1 and b.shape[-1] == K
+    ldb = b.stride(-2)
+    if out is None:
+        out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=a.device, dtype=torch.float32)
+    _lib.call("basd_gemm_nt", ptr, dt, sb, sn, sd, rpb, a_batch_stride, b.data_ptr(), ldb, b_batch_stride,
+              M, N, K, batch, out.data_ptr(), N, M * N, scale, _stream())
+    return out
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, mean_a: torch.Tensor | None = None,
+            mean_b: torch.Tensor | None = None, scale: float = 1.0, batch: int = 1, a_batch_stride: int = 0,
+            b_batch_stride: int = 0, krows: int | None = None, m_cols: int | None = None,
+            n_cols: int | None = None, split: bool = True) -> torch.Tensor:
+    """C = scale * (A - mean_a)^T (B - mean_b), contraction over rows.  A, B: (B,N,D) / (M,D) views."""
+    _require_cuda(a, b)
+    pa, dt, asb, asn, asd, rpb = _tok3(a)
+    pb, dtb, bsb, bsn, bsd, rpb_b = _tok3(b)
+    assert dt == dtb and rpb == rpb_b
+    kr = krows if krows is not None else (a.shape[0] * a.shape[1] if a.dim() == 3 else a.shape[0])
+    M = m_cols if m_cols is not None else a.shape[-1]
+    N = n_cols if n_cols is not None else b.shape[-1]
+    splits = _lib.query("basd_gemm_tn_splits", kr) if (split and batch == 1) else 1
+    out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=a.device, dtype=torch.float32)
+    slabs = torch.empty((batch * splits, M, N), device=a.device, dtype=torch.float32) if splits > 1 else None
+    _lib.call("basd_gemm_tn", pa, pb, dt, asb, asn, asd, a_batch_stride, bsb, bsn, bsd, b_batch_stride, rpb, kr, M, N,
+              batch, _ptr(mean_a), _ptr(mean_b), splits, _ptr(slabs), out.data_ptr(), N, M * N, scale, _stream())
+    return out
+
+
+def colmean(x: torch.Tensor) -> torch.Tensor:
+    """Column means of a (B,N,D) / (M,D) view -> (D,) fp32."""
+    _require_cuda(x)
+    ptr, dt, sb, sn, sd, rpb = _tok3(x)
+    rows = x.shape[0] * x.shape[1] if x.dim() == 3 else x.shape[0]
+    cols = x.shape[-1]
+    parts = _lib.query("basd_colmean_parts", rows)
+    partial = torch.empty((parts, cols), device=x.device, dtype=torch.float32)
+    mean = torch.empty((cols,), device=x.device, dtype=torch.float32)
+    _lib.call("basd_colmean", ptr, dt, sb, sn, sd, rpb, 0, rows, cols, 1, parts, partial.data_ptr(),
+              mean.data_ptr(), _stream())
+    return mean
+
+
+# --------------------------------------------------------------------------- #
+# Jacobi solver
+# --------------------------------------------------------------------------- #
+def jacobi_onesided(W: torch.Tensor, rows_dot: int, *, n_arr: torch.Tensor | None = None,
+                    want_sweeps: bool = False):
+    """In-place one-sided Jacobi on W: (batch, n, rows_tot) memory == column-major (rows_tot x n).
+    Returns column norms (batch, n) [and the sweep counts]."""
+    _require_cuda(W)
+    assert W.dtype == torch.float32 and W.is_contiguous() and W.dim() == 3
+    batch, n, rows_tot = W.shape
+    colnorm = torch.empty((batch, n), device=W.device, dtype=torch.float32)
+    flags = torch.empty((_lib.query("basd_jacobi_workspace_ints", batch, MAX_SWEEPS),), device=W.device,
+                        dtype=torch.int32)
+    sweeps = torch.zeros((batch,), device=W.device, dtype=torch.int32) if want_sweeps else None
+    _lib.call("basd_jacobi_onesided", W.data_ptr(), n * rows_tot, rows_dot, rows_tot, n, batch, _ptr(n_arr),
+              colnorm.data_ptr(), n, MAX_SWEEPS, flags.data_ptr(), _ptr(sweeps), _stream())
+    return (colnorm, sweeps) if want_sweeps else colnorm
+
+
+def sym_eig(G: torch.Tensor, kmax: int = 0) -> tuple[torch.Tensor, torch.Tensor | None, torch.Tensor, torch.Tensor]:
+    """Eigen-decomposition of symmetric PSD matrices G (batch, n, n); G is DESTROYED.
+    Returns (vals_desc (batch, n), vecs (batch, kmax, n) rows | None, W, colnorm) -- the last two let the
+    caller extract more vectors later without re-solving."""
+    assert G.dim() == 3 and G.shape[1] == G.shape[2]
+    colnorm = jacobi_onesided(G, G.shape[1])
+    vals, vecs = sort_extract(G, colnorm, kmax)
+    return vals, vecs, G, colnorm
+
+
+def sort_extract(W: torch.Tensor, colnorm: torch.Tensor, kmax: int, rows: int | None = None):
+    batch, n, rows_tot = W.shape
+    rows = rows_tot if rows is None else rows
+    vals = torch.empty((batch, n), device=W.device, dtype=torch.float32)
+    vecs = torch.empty((batch, kmax, rows), device=W.device, dtype=torch.float32) if kmax > 0 else None
+    _lib.call("basd_sort_extract", W.data_ptr(), n * rows_tot, rows, rows_tot, n, batch, colnorm.data_ptr(), n,
+              vals.data_ptr(), _ptr(vecs), kmax, _stream())
+    return vals, vecs
+
+
+def mp_rank_device(vals_desc: torch.Tensor, M: int, D: int, cap: int) -> torch.Tensor:
+    """Marchenko-Pastur ranks (int32, on device) from descending eigenvalues (batch, n)."""
+    q = D / M
+    factor = (1 + q ** 0.5) ** 2          # float64 on the host, as reference layer_selector.py:11,18
+    batch, n = vals_desc.shape
+    out = torch.empty((batch,), device=vals_desc.device, dtype=torch.int32)
+    _lib.call("basd_mp_rank", vals_desc.data_ptr(), n, batch, factor, cap, out.data_ptr(), None, _stream())
+    return out
+
+
+def grassmann_distance(colnorm: torch.Tensor, k_arr: torch.Tensor, sw: torch.Tensor,
+                       sw_index: torch.Tensor) -> torch.Tensor:
+    items, stride = colnorm.shape
+    d = torch.empty((items,), device=colnorm.device, dtype=torch.float32)
+    _lib.call("basd_grassmann_distance", colnorm.data_ptr(), stride, k_arr.data_ptr(), sw.data_ptr(), sw.stride(0),
+              sw_index.data_ptr(), items, d.data_ptr(), None, _stream())
+    return d
+
+
+def sqrt_clamp(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.call("basd_sqrt_clamp", x.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# interpolation taps (reference combined.py:9-14 / relational.py:29-32), host-side tables
+# --------------------------------------------------------------------------- #
+@dataclass(frozen=True)
+class Taps:
+    tap0: torch.Tensor    # (n_out,) int32
+    tap1: torch.Tensor    # (n_out,) int32
+    lam: torch.Tensor     # (n_out,) fp32
+    range0: torch.Tensor  # (n_in,) int32: first output row touching input row j
+    range1: torch.Tensor  # (n_in,) int32: one past the last
+
+
+@lru_cache(maxsize=64)
+def _taps_cpu(n_in: int, n_out: int):
+    i = torch.arange(n_out, dtype=torch.float32)
+    scale = torch.tensor(n_in, dtype=torch.float32) / torch.tensor(n_out, dtype=torch.float32)
+    src = torch.clamp(scale * (i + 0.5) - 0.5, min=0.0)
+    i0 = src.floor().to(torch.int64)
+    i1 = torch.clamp(i0 + 1, max=n_in - 1)
+    lam = src - i0.to(torch.float32)
+    r0 = torch.full((n_in,), n_out, dtype=torch.int64)
+    r1 = torch.zeros((n_in,), dtype=torch.int64)
+    for s in range(n_out):
+        for j in (int(i0[s]), int(i1[s])):
+            r0[j] = min(int(r0[j]), s)
+            r1[j] = max(int(r1[j]), s + 1)
+    r0 = torch.minimum(r0, r1)   # input rows no output touches get an empty range
+    return i0.to(torch.int32), i1.to(torch.int32), lam, r0.to(torch.int32), r1.to(torch.int32)
+
+
+_taps_dev: dict[tuple[int, int, str], Taps] = {}
+
+
+def taps(n_in: int, n_out: int, device: torch.device) -> Taps | None:
+    """None when the grids coincide (identity)."""
+    if n_in == n_out:
+        return None
+    key = (n_in, n_out, str(device))
+    if key not in _taps_dev:
+        _taps_dev[key] = Taps(*[t.to(device) for t in _taps_cpu(n_in, n_out)])
+    return _taps_dev[key]
+
+
+def _ptr_table(tensors: list[torch.Tensor]) -> torch.Tensor:
+    """Device array of base pointers (K8 of SURVEY.md: a pointer table instead of torch.stack)."""
+    host = torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64)
+    return host.to(tensors[0].device, non_blocking=True)
+
+
+# --------------------------------------------------------------------------- #
+# Procrustes forward / backward over all extraction layers
+# --------------------------------------------------------------------------- #
+@dataclass
+class ProcrustesContext:
+    omega: torch.Tensor      # (G, B, n_s)   G = E, or 1 when the teacher side is shared
+    mu_s: torch.Tensor       # (E, B, D_s)
+    a_prime: torch.Tensor    # (E, B, n, D_s)
+    k_prime: torch.Tensor    # (E, B, n, n)
+    tr_s: torch.Tensor       # (E, B)
+    tr_t: torch.Tensor       # (E, B)
+    nuc: torch.Tensor        # (E, B)
+    loss_b: torch.Tensor     # (E, B)
+    sweeps: torch.Tensor | None
+
+
+def _check_common_layout(tensors: list[torch.Tensor], what: str) -> list[torch.Tensor]:
+    ref = tensors[0]
+    out = []
+    for t in tensors:
+        if t.shape != ref.shape:
+            raise RuntimeError(f"all {what} must share one shape (reference stacks them): {t.shape} vs {ref.shape}")
+        if t.dtype != ref.dtype or t.stride() != ref.stride():
+            t = t.to(ref.dtype).contiguous()
+        out.append(t)
+    if any(o.stride() != out[0].stride() for o in out):
+        out = [o.contiguous() for o in out]
+    return out
+
+
+def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor], attns: list[torch.Tensor],
+                       mix: torch.Tensor, has_cls: bool, *, need_backward: bool = True,
+                       want_sweeps: bool = False) -> ProcrustesContext:
+    """students: E tensors (B, N_s, D_s); teachers: L tensors (B, N_t, D_t); attns: L tensors (B, H, A, A);
+    mix: (E, L) fp32 mixing weights on device.  Returns per-sample terms for every extraction layer."""
+    E, L = len(students), len(teachers)
+    students = [as_supported(s) for s in students]
+    students = [s if s.stride(2) == 1 else s.contiguous() for s in students]
+    teachers = _check_common_layout([as_supported(t) for t in teachers], "teacher token tensors")
+    attns = _check_common_layout([as_supported(a) for a in attns], "teacher attention tensors")
+    _require_cuda(*students, *teachers, *attns, mix)
+    dev = students[0].device
+    B, n_s, d_s = students[0].shape
+    _, n_t, d_t = teachers[0].shape
+    H, A = attns[0].shape[1], attns[0].shape[2]
+    n_a = A - (1 if has_cls else 0)
+    if n_t > n_s:
+        raise NotImplementedError("teacher grids finer than the student grid (N_t > N_s) are not supported yet")
+    n = n_t
+    tp = taps(n_t, n_s, dev)
+    t0, t1, lam = (tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr()) if tp else (None, None, None)
+    r0, r1 = (tp.range0.data_ptr(), tp.range1.data_ptr()) if tp else (None, None)
+    atp = taps(n_a, n_s, dev)
+    a0, a1, alam = (atp.tap0.data_ptr(), atp.tap1.data_ptr(), atp.lam.data_ptr()) if atp else (None, None, None)
+    st = _stream()
+    mix = mix.contiguous().float()
+    shared = L == 1            # softmax over one layer is exactly 1: the teacher side is identical for all e
+    G = 1 if shared else E
+    tok_tab, att_tab = _ptr_table(teachers), _ptr_table(attns)
+    f32 = dict(device=dev, dtype=torch.float32)
+    omega = torch.empty((G, B, n_s), **f32)
+    omega_t = torch.empty((G, B, n_t), **f32)
+    mu_t = torch.empty((G, B, d_t), **f32)
+    tc = torch.empty((G, B, n, d_t), **f32)
+    sb, sh, sq, sk = attns[0].stride()
+    tsb, tsn, tsd = teachers[0].stride()
+    for g in range(G):
+        _lib.call("basd_token_weights", att_tab.data_ptr(), _dtype_code(attns[0]), mix[g].data_ptr(), L, sb, sh, sq,
+                  sk, B, H, A, int(has_cls), n_a, n_t, n_s, a0, a1, alam, t0, t1, lam, omega[g].data_ptr(),
+                  omega_t[g].data_ptr(), None, st)
+        _lib.call("basd_teacher_center", tok_tab.data_ptr(), _dtype_code(teachers[0]), mix[g].data_ptr(), L, tsb,
+                  tsn, tsd, B, n_t, d_t, omega_t[g].data_ptr(), mu_t[g].data_ptr(), tc[g].data_ptr(), st)
+    mu_s = torch.empty((E, B, d_s), **f32)
+    tr_s = torch.empty((E, B), **f32)
+    a_prime = torch.empty((E, B, n, d_s), **f32)
+    for e, x in enumerate(students):
+        _lib.call("basd_student_project", x.data_ptr(), _dtype_code(x), x.stride(0), x.stride(1), B, n_s, n_t, d_s,
+                  omega[0 if shared else e].data_ptr(), t0, t1, lam, r0, r1, mu_s[e].data_ptr(), tr_s[e].data_ptr(),
+                  a_prime[e].data_ptr(), st)
+    # fp64 Grams on the teacher grid, Cholesky factors, stacked product
+    g_all = torch.empty((E * B + G * B, n, n), device=dev, dtype=torch.float64)
+    _lib.call("basd_gram_f64", a_prime.data_ptr(), n * d_s, n, d_s, E * B, g_all.data_ptr(), n * n, st)
+    _lib.call("basd_gram_f64", tc.data_ptr(), n * d_t, n, d_t, G * B, g_all[E * B:].data_ptr(), n * n, st)
+    l_all = torch.empty_like(g_all)
+    _lib.call("basd_chol_f64", g_all.data_ptr(), n * n, n, E * B + G * B, l_all.data_ptr(), n * n, st)
+    l_a = l_all[:E * B]
+    g_b = g_all[E * B:]
+    l_b = l_all[E * B:]
+    if shared and E > 1:
+        l_b = l_b.repeat(E, 1, 1)
+        g_b = g_b.repeat(E, 1, 1)
+        omega_e = omega.expand(E, B, n_s).contiguous()
+    else:
+        omega_e = omega
+    W = torch.empty((E * B, n, 2 * n), **f32)      # memory == column-major (2n x n)
+    _lib.call("basd_stack_product", l_a.data_ptr(), l_b.data_ptr(), n * n, n, E * B, W.data_ptr(), 2 * n * n, st)
+    res = jacobi_onesided(W, n, want_sweeps=want_sweeps)
+    sigma, sweeps = res if want_sweeps else (res, None)
+    tr_t = torch.empty((E, B), **f32)
+    nuc = torch.empty((E, B), **f32)
+    loss_b = torch.empty((E, B), **f32)
+    k_prime = torch.empty((E, B, n, n), **f32) if need_backward else None
+    _lib.call("basd_procrustes_finalize", W.data_ptr(), 2 * n * n, sigma.data_ptr(), n, n_s, E * B, g_b.data_ptr(),
+              n * n, omega_e.data_ptr(), t0, t1, lam, tr_s.data_ptr(), tr_t.data_ptr(), nuc.data_ptr(),
+              loss_b.data_ptr(), _ptr(k_prime), st)
+    return ProcrustesContext(omega, mu_s, a_prime, k_prime, tr_s, tr_t, nuc, loss_b, sweeps)
+
+
+def procrustes_student_grads(students: list[torch.Tensor], ctx: ProcrustesContext,
+                             grad_layers: torch.Tensor) -> list[torch.Tensor]:
+    """d(sum_e grad_layers[e] * mean_b loss_b[e]) / d students[e]   (fp32, contiguous)."""
+    E = len(students)
+    _, B, n, d_s = ctx.a_prime.shape
+    dev = ctx.a_prime.device
+    n_s = students[0].shape[1]
+    tp = taps(n, n_s, dev)
+    t0, t1, lam = (tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr()) if tp else (None, None, None)
+    st = _stream()
+    # H = K' A' per (layer, sample): K' is symmetric, so this is the TN contraction
+    kp = ctx.k_prime.view(E * B, n, n)
+    ap = ctx.a_prime.view(E * B, n, d_s)
+    h = gemm_tn(kp[0], ap[0], batch=E * B, a_batch_stride=n * n, b_batch_stride=n * d_s, krows=n, m_cols=n,
+                n_cols=d_s, split=False).view(E, B, n, d_s)
+    grad_layers = grad_layers.contiguous().float()
+    grads = []
+    shared = ctx.omega.shape[0] == 1
+    for e, x in enumerate(students):
+        x = as_supported(x)
+        x = x if x.stride(2) == 1 else x.contiguous()
+        dx = torch.empty((B, n_s, d_s), device=dev, dtype=torch.float32)
+        _lib.call("basd_student_grad", x.data_ptr(), _dtype_code(x), x.stride(0), x.stride(1), B, n_s, n, d_s,
+                  ctx.omega[0 if shared else e].data_ptr(), ctx.mu_s[e].data_ptr(), h[e].data_ptr(), t0, t1, lam,
+                  grad_layers[e:e + 1].data_ptr(), 2.0 / B, dx.data_ptr(), st)
+        grads.append(dx)
+    return grads

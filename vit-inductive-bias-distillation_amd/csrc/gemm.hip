@@ -1,0 +1,402 @@
+// fp32-in / fp32-accumulate MFMA contractions for the BASD loss path.
+//
+//   reference call sites replaced:
+//     tokens.reshape(-1, D_t) @ proj_t.T          src/losses/layer_selector.py:72, :135   (gemm_nt)
+//     features.T @ features / M  (and x @ x.T)    src/losses/layer_selector.py:13, :15    (gemm_tn / gemm_nt)
+//     centred z^T z feeding the thin SVD           src/losses/layer_selector.py:35-36, :90-92 (gemm_tn with mean)
+//     U_s.T @ U_t                                  src/losses/layer_selector.py:99          (gemm_nt)
+//
+// Both kernels use v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 157 TFLOP/s peak
+// on MI355X): a 128x128 block tile, 4 waves as 2x2, each wave 2x2 MFMA tiles.
+//
+//   gemm_nt : C[M,N] = A[M,K] * B[N,K]^T     K contiguous in both operands.
+//             LDS image [row][k] padded to 36 floats, fragments by ds_read_b128:
+//             one 16-byte read feeds four k-steps (lane half h takes k = 8g+4h+s,
+//             the same permutation for A and B, so the sum over k is unchanged).
+//   gemm_tn : C[M,N] = A[K,M]^T * B[K,N]     contraction index is the slow one
+//             (Gram matrices over tokens).  LDS image [k][m], fragments by
+//             ds_read_b32 (lanes along m: conflict-free).  Optional per-column
+//             mean subtraction while staging, split over K with one slab per
+//             split (deterministic reduction by reduce_slabs_kernel).
+#include "basd_common.h"
+
+namespace basd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128;
+
+struct GemmOperand {
+    const void* ptr;
+    long sb, sn, sd;     // (batch, row-in-batch, column) strides in elements
+    int rows_per_batch;  // rows are indexed m = b * rows_per_batch + n
+    long batch_stride;   // extra stride for blockIdx.z-batched problems (elements)
+};
+
+__device__ __forceinline__ long row_off(const GemmOperand& o, long m) {
+    const long b = m / o.rows_per_batch, n = m - b * o.rows_per_batch;
+    return b * o.sb + n * o.sn;
+}
+
+__device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int M, int N, int m0, int n0,
+                                           const f32x16 (&acc)[2][2], int wm, int wn, int lane, float scale) {
+    const int col_l = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + col_l;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row < M) C[(long)row * ldc + col] = acc[mi][ni][r] * scale;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// NT: grid = (ceil(N/128), ceil(M/128), batch), block = 256
+// ---------------------------------------------------------------------------
+constexpr int NT_BK = 32, NT_LD = 36;
+
+template <typename TA, bool VEC>
+__device__ __forceinline__ void nt_load(const GemmOperand& o, int rows_total, int K, int row0, int k0, int tid,
+                                        float (&reg)[4][4]) {
+    const TA* base = (const TA*)o.ptr;
+    if (VEC) {
+        // lane -> (row, 4 consecutive k): 8 lanes cover one 128-byte row segment
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j, row = row0 + (f >> 3), k = k0 + (f & 7) * 4;
+            if (row < rows_total && k + 3 < K) {
+                const TA* p = base + row_off(o, row) + (long)k * o.sd;
+                if (sizeof(TA) == 4) {
+                    const float4 v = *(const float4*)p;
+                    reg[j][0] = v.x; reg[j][1] = v.y; reg[j][2] = v.z; reg[j][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) reg[j][c] = to_f32(p[c]);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int kk = k + c;
+                    reg[j][c] = (row < rows_total && kk < K) ? to_f32(base[row_off(o, row) + (long)kk * o.sd]) : 0.f;
+                }
+            }
+        }
+    } else {
+        // lanes along rows (row-contiguous / generic layouts): f -> (k = f / 128, row = f % 128)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int f = tid + 256 * (j * 4 + c), row = row0 + (f & 127), k = k0 + (f >> 7);
+                reg[j][c] = (row < rows_total && k < K) ? to_f32(base[row_off(o, row) + (long)k * o.sd]) : 0.f;
+            }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void nt_store_lds(float* __restrict__ tile, int tid, const float (&reg)[4][4]) {
+    if (VEC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j;
+            *(float4*)(tile + (f >> 3) * NT_LD + (f & 7) * 4) = make_float4(reg[j][0], reg[j][1], reg[j][2], reg[j][3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int f = tid + 256 * (j * 4 + c);
+                tile[(f & 127) * NT_LD + (f >> 7)] = reg[j][c];
+            }
+    }
+}
+
+template <typename TA, bool VEC_A>
+__global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand B, int M, int N, int K,
+                                                      float* __restrict__ C, long ldc, long c_batch_stride,
+                                                      float scale) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 128 * NT_LD];
+    float* tA = lds;
+    float* tB = lds + 128 * NT_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    A.ptr = (const TA*)A.ptr + (long)blockIdx.z * A.batch_stride;
+    B.ptr = (const float*)B.ptr + (long)blockIdx.z * B.batch_stride;
+    C += (long)blockIdx.z * c_batch_stride;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[4][4], rb[4][4];
+    nt_load<TA, VEC_A>(A, M, K, m0, 0, tid, ra);
+    nt_load<float, true>(B, N, K, n0, 0, tid, rb);
+    const int i = lane & 31, h = lane >> 5;
+    for (int k0 = 0; k0 < K; k0 += NT_BK) {
+        __syncthreads();
+        nt_store_lds<VEC_A>(tA, tid, ra);
+        nt_store_lds<true>(tB, tid, rb);
+        __syncthreads();
+        if (k0 + NT_BK < K) {
+            nt_load<TA, VEC_A>(A, M, K, m0, k0 + NT_BK, tid, ra);
+            nt_load<float, true>(B, N, K, n0, k0 + NT_BK, tid, rb);
+        }
+#pragma unroll
+        for (int g = 0; g < NT_BK / 8; ++g) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const float4*)(tA + (wm * 64 + mi * 32 + i) * NT_LD + g * 8 + 4 * h);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const float4*)(tB + (wn * 64 + ni * 32 + i) * NT_LD + g * 8 + 4 * h);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+    }
+    store_tile(C, ldc, M, N, m0, n0, acc, wm, wn, lane, scale);
+}
+
+// ---------------------------------------------------------------------------
+// TN: grid = (ceil(N/128), ceil(M/128), batch * splits), block = 256
+//   A: (Krows x M), B: (Krows x N); contraction over rows [k_begin, k_end) of the split.
+//   out: slab (split) or batch element: C + z * c_z_stride.
+// ---------------------------------------------------------------------------
+constexpr int TN_BK = 16, TN_LD = 128;
+
+template <typename T>
+__device__ __forceinline__ void tn_load(const GemmOperand& o, int krows_end, int cols, int k0, int col0, int tid,
+                                        const float* __restrict__ mean, float (&reg)[2][4]) {
+    const T* base = (const T*)o.ptr;
+    // f -> (k = f / 32, 4 consecutive columns): 32 lanes cover one 512-byte row segment
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = tid + 256 * j, k = k0 + (f >> 5), c = col0 + (f & 31) * 4;
+        if (k < krows_end) {
+            const T* p = base + row_off(o, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int cc = c + e;
+                reg[j][e] = cc < cols ? to_f32(p[(long)cc * o.sd]) - (mean ? mean[cc] : 0.f) : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) reg[j][e] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void tn_store_lds(float* __restrict__ tile, int tid, const float (&reg)[2][4]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = tid + 256 * j;
+        *(float4*)(tile + (f >> 5) * TN_LD + (f & 31) * 4) = make_float4(reg[j][0], reg[j][1], reg[j][2], reg[j][3]);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(GemmOperand A, GemmOperand B, int M, int N, int Krows,
+                                                      int splits, const float* __restrict__ mean_a,
+                                                      const float* __restrict__ mean_b, float* __restrict__ C,
+                                                      long ldc, long c_z_stride, float scale) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * TN_BK * TN_LD];
+    float* tA = lds;
+    float* tB = lds + TN_BK * TN_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int bz = blockIdx.z / splits, sp = blockIdx.z - bz * splits;
+    A.ptr = (const T*)A.ptr + (long)bz * A.batch_stride;
+    B.ptr = (const T*)B.ptr + (long)bz * B.batch_stride;
+    C += (long)blockIdx.z * c_z_stride;
+    // rows of this split, in multiples of TN_BK
+    const int chunks = (Krows + TN_BK - 1) / TN_BK;
+    const int per = (chunks + splits - 1) / splits;
+    const int k_begin = sp * per * TN_BK;
+    int k_end = k_begin + per * TN_BK;
+    if (k_end > Krows) k_end = Krows;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[2][4], rb[2][4];
+    if (k_begin < k_end) {
+        tn_load<T>(A, k_end, M, k_begin, m0, tid, mean_a, ra);
+        tn_load<T>(B, k_end, N, k_begin, n0, tid, mean_b, rb);
+    }
+    const int i = lane & 31, h = lane >> 5;
+    for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
+        __syncthreads();
+        tn_store_lds(tA, tid, ra);
+        tn_store_lds(tB, tid, rb);
+        __syncthreads();
+        if (k0 + TN_BK < k_end) {
+            tn_load<T>(A, k_end, M, k0 + TN_BK, m0, tid, mean_a, ra);
+            tn_load<T>(B, k_end, N, k0 + TN_BK, n0, tid, mean_b, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < TN_BK; kk += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = tA[(kk + h) * TN_LD + wm * 64 + mi * 32 + i];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = tB[(kk + h) * TN_LD + wn * 64 + ni * 32 + i];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    store_tile(C, ldc, M, N, m0, n0, acc, wm, wn, lane, scale);
+}
+
+// out[i] = scale * sum_s slabs[s][i]   (fixed order: deterministic)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, long slab_stride, int splits, long count,
+                                    float scale, float* __restrict__ out, long batch_in_stride,
+                                    long batch_out_stride) {
+    const float* in = slabs + (long)blockIdx.y * batch_in_stride;
+    float* o = out + (long)blockIdx.y * batch_out_stride;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += in[(long)k * slab_stride + i];
+        o[i] = s * scale;
+    }
+}
+
+// Column means of a (rows x cols) strided token matrix: two-stage, deterministic.
+//   stage 1: grid = (ceil(cols/256), parts, batch) partial sums; stage 2 folds the parts.
+template <typename T>
+__global__ void colsum_partial_kernel(GemmOperand X, int rows, int cols, int parts, float* __restrict__ partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const T* base = (const T*)X.ptr + (long)blockIdx.z * X.batch_stride;
+    const int per = (rows + parts - 1) / parts;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += to_f32(base[row_off(X, r) + (long)c * X.sd]);
+    partial[((long)blockIdx.z * parts + blockIdx.y) * cols + c] = s;
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int cols, int parts, float inv_rows,
+                                    float* __restrict__ mean) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const float* p = partial + (long)blockIdx.y * parts * cols;
+    float s = 0.f;
+    for (int k = 0; k < parts; ++k) s += p[(long)k * cols + c];
+    mean[(long)blockIdx.y * cols + c] = s * inv_rows;
+}
+
+}  // namespace basd
+
+using namespace basd;
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" {
+
+// C[z] (M x N, ldc) = scale * A[z] (M x K) * B[z]^T (N x K).
+//   A: element (m, k) at a + z*a_batch_stride + (m / a_rows_per_batch)*a_sb + (m % a_rows_per_batch)*a_sn + k*a_sd,
+//      dtype fp32 or bf16.   B: fp32, row-major with leading dimension ldb.
+int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, int a_rows_per_batch,
+                 long a_batch_stride, const float* b, long ldb, long b_batch_stride, int M, int N, int K, int batch,
+                 float* c, long ldc, long c_batch_stride, float scale, hipStream_t stream) {
+    BASD_CHECK_ARG(a && b && c && M > 0 && N > 0 && K > 0 && batch > 0 && a_rows_per_batch > 0);
+    BASD_CHECK_ARG(aligned16(b) && ldb % 4 == 0 && b_batch_stride % 4 == 0);
+    GemmOperand A{a, a_sb, a_sn, a_sd, a_rows_per_batch, a_batch_stride};
+    GemmOperand B{b, 0, ldb, 1, 1 << 30, b_batch_stride};
+    const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+    if (a_dtype == BASD_DTYPE_F32) {
+        const bool vec = a_sd == 1 && aligned16(a) && a_sb % 4 == 0 && a_sn % 4 == 0 && a_batch_stride % 4 == 0;
+        if (vec) gemm_nt_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale);
+        else gemm_nt_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale);
+    } else if (a_dtype == BASD_DTYPE_BF16) {
+        if (a_sd == 1) gemm_nt_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale);
+        else gemm_nt_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale);
+    } else {
+        return BASD_EINVAL;
+    }
+    BASD_RETURN_LAST();
+}
+
+int basd_gemm_tn_splits(int krows) {
+    int s = krows / 512;
+    if (s < 1) s = 1;
+    if (s > 32) s = 32;
+    return s;
+}
+
+// C[z] (M x N) = scale * (A[z] - 1 mean_a^T)^T (B[z] - 1 mean_b^T), contraction over `krows` rows.
+//   A element (k, m) at a + z*a_batch_stride + (k / rows_per_batch)*sb + (k % rows_per_batch)*sn + m*sd; B likewise
+//   with its own base/strides; both share dtype.  `slabs` (nullable when splits == 1) holds
+//   batch*splits*M*N floats of scratch.
+int basd_gemm_tn(const void* a, const void* b, int dtype, long a_sb, long a_sn, long a_sd, long a_batch_stride,
+                 long b_sb, long b_sn, long b_sd, long b_batch_stride, int rows_per_batch, int krows, int M, int N,
+                 int batch, const float* mean_a, const float* mean_b, int splits, float* slabs, float* c, long ldc,
+                 long c_batch_stride, float scale, hipStream_t stream) {
+    BASD_CHECK_ARG(a && b && c && krows > 0 && M > 0 && N > 0 && batch > 0 && splits >= 1 && rows_per_batch > 0);
+    BASD_CHECK_ARG(splits == 1 || (slabs != nullptr && ldc == N));
+    GemmOperand A{a, a_sb, a_sn, a_sd, rows_per_batch, a_batch_stride};
+    GemmOperand B{b, b_sb, b_sn, b_sd, rows_per_batch, b_batch_stride};
+    const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch * splits);
+    float* out = splits == 1 ? c : slabs;
+    const long out_ld = splits == 1 ? ldc : N;
+    const long z_stride = splits == 1 ? c_batch_stride : (long)M * N;
+    const float k_scale = splits == 1 ? scale : 1.f;
+    if (dtype == BASD_DTYPE_F32)
+        gemm_tn_kernel<float><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+    else if (dtype == BASD_DTYPE_BF16)
+        gemm_tn_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+    else
+        return BASD_EINVAL;
+    if (splits > 1) {
+        const long count = (long)M * N;
+        int blocks = (int)((count + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        reduce_slabs_kernel<<<dim3(blocks, batch), 256, 0, stream>>>(slabs, count, splits, count, scale, c,
+                                                                    (long)splits * count, c_batch_stride);
+    }
+    BASD_RETURN_LAST();
+}
+
+int basd_colmean_parts(int rows) {
+    int p = rows / 256;
+    if (p < 1) p = 1;
+    if (p > 64) p = 64;
+    return p;
+}
+
+// mean[z][c] = (1/rows) sum_r X[z](r, c).  `partial`: batch*parts*cols floats of scratch.
+int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_per_batch, long batch_stride,
+                 int rows, int cols, int batch, int parts, float* partial, float* mean, hipStream_t stream) {
+    BASD_CHECK_ARG(x && partial && mean && rows > 0 && cols > 0 && batch > 0 && parts >= 1);
+    GemmOperand X{x, sb, sn, sd, rows_per_batch, batch_stride};
+    const dim3 grid((cols + 255) / 256, parts, batch);
+    if (dtype == BASD_DTYPE_F32) colsum_partial_kernel<float><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial);
+    else if (dtype == BASD_DTYPE_BF16) colsum_partial_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial);
+    else return BASD_EINVAL;
+    colsum_final_kernel<<<dim3((cols + 255) / 256, batch), 256, 0, stream>>>(partial, cols, parts, 1.f / rows, mean);
+    BASD_RETURN_LAST();
+}
+
+}  // extern "C"

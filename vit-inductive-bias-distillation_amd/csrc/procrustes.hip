@@ -1,0 +1,674 @@
+// Attention-weighted Procrustes loss (reference src/losses/relational.py:5-50 together with the
+// token-count interpolation of src/losses/combined.py:9-14 and the soft teacher-layer mixing of
+// src/losses/layer_selector.py:110-112) on MI355X.
+//
+// The reference forms, per sample, C = S_w^T T_w (D_s x D_t, e.g. 384 x 2048) and takes its
+// nuclear norm through a LAPACK SVD.  Here the same number is obtained from n x n matrices,
+// n = N_t (teacher tokens, 49 / 196 / 144 at the BASELINE configs):
+//
+//   T_w = E T_c,  E = diag(sqrt w) I_interp  (N_s x N_t),  T_c = mixed teacher, weighted-centred
+//   C   = S_w^T E T_c = A'^T T_c            with A' = E^T S_w   (N_t x D_s)
+//   sigma(C) = sigma(L_a^T L_b)             with A'A'^T = L_a L_a^T,  T_c T_c^T = L_b L_b^T
+//
+// The two Gram matrices are accumulated in fp64 on the f64 MFMA (products of fp32 inputs are
+// exact in fp64, so squaring the condition number costs nothing), factored in fp64, and only
+// the n x n product M = L_a^T L_b is handed to the fp32 one-sided Jacobi solver (jacobi.hip),
+// stacked on top of L_b so that Y = L_b V comes out of the same rotations.  Backward needs
+//   d nuc / d A' = K' A',   K' = Y Sigma^+ Y^T   (n x n, symmetric PSD)
+// which the finalize kernel emits; the student-token gradient is then a streaming pass.
+#include "basd_common.h"
+
+namespace basd {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// Token weights (relational.py:22-34) from the layer-mixed attention (layer_selector.py:112).
+// grid = B, block = 256.
+//   attn[l]: (B, H, A, A) with element strides (sb, sh, sq, sk); A = n_a + has_cls
+//   atap*  : interpolation n_a -> n_s of the weights (relational.py:29-32), null when n_a == n_s
+//   tap*   : interpolation n_t -> n_s of the teacher TOKENS (combined.py:9-14), null when n_t == n_s
+//            (inside BASDLoss n_a == n_t; the stand-alone loss may get aligned tokens + raw attention)
+//   omega  : (B, n_s) normalised weights on the student grid
+//   omega_t: (B, n_t) = I_tok^T omega   (weights folded back onto the teacher token grid)
+//   raw_out: (B, n_a) un-normalised attention-grid weights (kept for backward), nullable
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) token_weights_kernel(const void* const* __restrict__ attn_ptrs,
+                                                            const float* __restrict__ mix, int L, long sb, long sh,
+                                                            long sq, long sk, int H, int A, int has_cls, int n_a,
+                                                            int n_t, int n_s, const int* __restrict__ atap0,
+                                                            const int* __restrict__ atap1,
+                                                            const float* __restrict__ alam,
+                                                            const int* __restrict__ tap0,
+                                                            const int* __restrict__ tap1,
+                                                            const float* __restrict__ lam, float* __restrict__ omega,
+                                                            float* __restrict__ omega_t, float* __restrict__ raw_out) {
+    extern __shared__ float sm[];
+    float* raw = sm;            // n_a
+    float* w = sm + n_a;        // n_s
+    __shared__ float red[32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < n_a; j += blockDim.x) {
+        float acc = 0.f;
+        if (has_cls) {
+            for (int h = 0; h < H; ++h) {
+                float m = 0.f;
+                for (int l = 0; l < L; ++l)
+                    m += mix[l] * to_f32(((const T*)attn_ptrs[l])[b * sb + h * sh + (long)(1 + j) * sk]);
+                acc += m;
+            }
+            acc /= (float)H;
+        } else {
+            for (int h = 0; h < H; ++h)
+                for (int q = 0; q < A; ++q) {
+                    float m = 0.f;
+                    for (int l = 0; l < L; ++l)
+                        m += mix[l] * to_f32(((const T*)attn_ptrs[l])[b * sb + h * sh + q * sq + (long)j * sk]);
+                    acc += m;
+                }
+            acc /= (float)(H * A);
+        }
+        raw[j] = acc;
+        if (raw_out) raw_out[(long)b * n_a + j] = acc;
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int n = tid; n < n_s; n += blockDim.x) {
+        float v;
+        if (atap0) {
+            const float l1 = alam[n];
+            v = (1.f - l1) * raw[atap0[n]] + l1 * raw[atap1[n]];
+        } else {
+            v = raw[n];
+        }
+        w[n] = v;
+        part += v;
+    }
+    const float total = block_sum(part, red);
+    for (int n = tid; n < n_s; n += blockDim.x) {
+        const float v = w[n] / total;
+        w[n] = v;
+        omega[(long)b * n_s + n] = v;
+    }
+    __syncthreads();
+    for (int j = tid; j < n_t; j += blockDim.x) {
+        float acc = 0.f;
+        if (tap0) {
+            for (int n = 0; n < n_s; ++n) {
+                const float l1 = lam[n];
+                if (tap0[n] == j) acc += (1.f - l1) * w[n];
+                if (tap1[n] == j) acc += l1 * w[n];
+            }
+        } else {
+            acc = w[j];
+        }
+        omega_t[(long)b * n_t + j] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Student side: weighted mean, trace, and the down-projection A' = I^T diag(w) (X - 1 mu^T).
+// grid = B, block = 256.   X: (B, N_s, D) strided (feature stride 1).
+//   range0/range1: for teacher token j, student rows [range0[j], range1[j]) touch it (null = identity grid)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) student_project_kernel(const T* __restrict__ X, long sb, long sn, int n_s,
+                                                              int n_t, int D, const float* __restrict__ omega,
+                                                              const int* __restrict__ tap0,
+                                                              const int* __restrict__ tap1,
+                                                              const float* __restrict__ lam,
+                                                              const int* __restrict__ range0,
+                                                              const int* __restrict__ range1,
+                                                              float* __restrict__ mu_out, float* __restrict__ tr_out,
+                                                              float* __restrict__ Ap) {
+    extern __shared__ float sm[];
+    float* mu = sm;        // D
+    float* w = sm + D;     // n_s
+    __shared__ float red[32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const T* Xb = X + (long)b * sb;
+    for (int n = tid; n < n_s; n += 256) w[n] = omega[(long)b * n_s + n];
+    __syncthreads();
+    for (int d = tid; d < D; d += 256) {
+        float acc = 0.f;
+        for (int n = 0; n < n_s; ++n) acc = fmaf(w[n], to_f32(Xb[(long)n * sn + d]), acc);
+        mu[d] = acc;
+        mu_out[(long)b * D + d] = acc;
+    }
+    __syncthreads();
+    // trace: sum_n w_n |x_n - mu|^2
+    float part = 0.f;
+    for (int n = 0; n < n_s; ++n) {
+        float rowacc = 0.f;
+        for (int d = tid; d < D; d += 256) {
+            const float c = to_f32(Xb[(long)n * sn + d]) - mu[d];
+            rowacc = fmaf(c, c, rowacc);
+        }
+        part = fmaf(w[n], rowacc, part);
+    }
+    const float tr = block_sum(part, red);
+    if (tid == 0) tr_out[b] = tr;
+    // A'[j, :] = sum_n I[n, j] w_n (x_n - mu)
+    float* Ab = Ap + (long)b * n_t * D;
+    for (int j = 0; j < n_t; ++j) {
+        const int n0 = range0 ? range0[j] : j, n1 = range1 ? range1[j] : j + 1;
+        for (int d = tid; d < D; d += 256) {
+            float acc = 0.f;
+            for (int n = n0; n < n1; ++n) {
+                float coef;
+                if (tap0) {
+                    const float l1 = lam[n];
+                    coef = (tap0[n] == j ? 1.f - l1 : 0.f) + (tap1[n] == j ? l1 : 0.f);
+                } else {
+                    coef = 1.f;
+                }
+                acc = fmaf(coef * w[n], to_f32(Xb[(long)n * sn + d]) - mu[d], acc);
+            }
+            Ab[(long)j * D + d] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Teacher side: mix the L layers, weighted-centre on the teacher grid.
+//   Tc[b, j, :] = sum_l mix_l T_l[b, j, :] - sum_j' omega_t[j'] (sum_l mix_l T_l[b, j', :])
+// grid = (ceil(D/64), B), block = 256.  Handles feature-contiguous (sd == 1) and
+// channel-major (sn == 1) teachers through an LDS tile of 64 features x n_t tokens.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) teacher_center_kernel(const void* const* __restrict__ tok_ptrs,
+                                                             const float* __restrict__ mix, int L, long sb, long sn,
+                                                             long sd, int n_t, int D,
+                                                             const float* __restrict__ omega_t,
+                                                             float* __restrict__ mu_out, float* __restrict__ Tc) {
+    extern __shared__ float sm[];
+    float* tile = sm;                    // n_t x 65
+    float* wt = sm + (size_t)n_t * 65;   // n_t
+    float* mu = wt + n_t;                // 64
+    const int b = blockIdx.y, d0 = blockIdx.x * 64, tid = threadIdx.x;
+    for (int j = tid; j < n_t; j += 256) wt[j] = omega_t[(long)b * n_t + j];
+    const int total = n_t * 64;
+    if (sd == 1) {
+        for (int idx = tid; idx < total; idx += 256) {
+            const int j = idx >> 6, dd = idx & 63, d = d0 + dd;
+            float acc = 0.f;
+            if (d < D)
+                for (int l = 0; l < L; ++l)
+                    acc = fmaf(mix[l], to_f32(((const T*)tok_ptrs[l])[b * sb + (long)j * sn + d]), acc);
+            tile[j * 65 + dd] = acc;
+        }
+    } else {
+        for (int idx = tid; idx < total; idx += 256) {
+            const int dd = idx / n_t, j = idx - dd * n_t, d = d0 + dd;
+            float acc = 0.f;
+            if (d < D)
+                for (int l = 0; l < L; ++l)
+                    acc = fmaf(mix[l], to_f32(((const T*)tok_ptrs[l])[b * sb + (long)j * sn + (long)d * sd]), acc);
+            tile[j * 65 + dd] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float acc = 0.f;
+        for (int j = 0; j < n_t; ++j) acc = fmaf(wt[j], tile[j * 65 + tid], acc);
+        mu[tid] = acc;
+        if (d0 + tid < D) mu_out[(long)b * D + d0 + tid] = acc;
+    }
+    __syncthreads();
+    float* out = Tc + (long)b * n_t * D;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int j = idx >> 6, dd = idx & 63, d = d0 + dd;
+        if (d < D) out[(long)j * D + d] = tile[j * 65 + dd] - mu[dd];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Batched Gram in fp64 on the f64 MFMA: G[b] = P[b] P[b]^T, P: (n x D) fp32 row-major.
+// grid = batch, block = 64 * waves.  Lower tiles (16 x 16) are dealt round-robin to waves.
+// v_mfma_f64_16x16x4_f64: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15];
+// D: col = l & 15, row = (l >> 4) + 4 * reg.
+// ---------------------------------------------------------------------------
+constexpr int G64_BK = 32, G64_LD = 36, G64_TPW = 8;
+
+__global__ void __launch_bounds__(1024) gram_f64_kernel(const float* __restrict__ P, long p_batch_stride, int n, int D,
+                                                        double* __restrict__ G, long g_batch_stride) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // (nt*16) x G64_LD
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int nt = (n + 15) / 16, ntiles = nt * (nt + 1) / 2;
+    const float* Pb = P + (long)b * p_batch_stride;
+    f64x4 acc[G64_TPW];
+#pragma unroll
+    for (int t = 0; t < G64_TPW; ++t) acc[t] = f64x4{0., 0., 0., 0.};
+    // tile list of this wave: linear lower-triangular index -> (ti, tj), ti >= tj
+    int ti[G64_TPW], tj[G64_TPW];
+#pragma unroll
+    for (int t = 0; t < G64_TPW; ++t) {
+        const int lin = wave + t * nw;
+        int r = 0;
+        if (lin < ntiles) {
+            r = (int)((sqrtf(8.f * lin + 1.f) - 1.f) * 0.5f);
+            while ((r + 1) * (r + 2) / 2 <= lin) ++r;
+            while (r * (r + 1) / 2 > lin) --r;
+            ti[t] = r;
+            tj[t] = lin - r * (r + 1) / 2;
+        } else {
+            ti[t] = -1;
+            tj[t] = -1;
+        }
+    }
+    const int rows_pad = nt * 16;
+    const int i16 = lane & 15, kq = lane >> 4;
+    for (int k0 = 0; k0 < D; k0 += G64_BK) {
+        __syncthreads();
+        for (int idx = tid; idx < rows_pad * (G64_BK / 4); idx += blockDim.x) {
+            const int r = idx / (G64_BK / 4), c4 = (idx - r * (G64_BK / 4)) * 4, k = k0 + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < n) {
+                const float* p = Pb + (long)r * D + k;
+                if (k + 3 < D) {
+                    v = *(const float4*)p;
+                } else {
+                    if (k < D) v.x = p[0];
+                    if (k + 1 < D) v.y = p[1];
+                    if (k + 2 < D) v.z = p[2];
+                }
+            }
+            *(float4*)(tile + r * G64_LD + c4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G64_BK / 16; ++g) {
+#pragma unroll
+            for (int t = 0; t < G64_TPW; ++t) {
+                if (ti[t] < 0) continue;
+                const float4 a = *(const float4*)(tile + (ti[t] * 16 + i16) * G64_LD + g * 16 + 4 * kq);
+                const float4 bb = *(const float4*)(tile + (tj[t] * 16 + i16) * G64_LD + g * 16 + 4 * kq);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a.x, (double)bb.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a.y, (double)bb.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a.z, (double)bb.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a.w, (double)bb.w, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    double* Gb = G + (long)b * g_batch_stride;
+#pragma unroll
+    for (int t = 0; t < G64_TPW; ++t) {
+        if (ti[t] < 0) continue;
+        const int col = tj[t] * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = ti[t] * 16 + (lane >> 4) + 4 * r;
+            if (row < n && col < n) {
+                Gb[(long)row * n + col] = acc[t][r];
+                Gb[(long)col * n + row] = acc[t][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fp64 Cholesky of symmetric PSD matrices (possibly singular): G = L L^T, packed in LDS.
+// grid = batch, block = 256..1024.  A pivot below n*1e-15*max_diag zeroes its column.
+// L is written full (n x n row-major, zeros above the diagonal).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int pk(int i, int j, int n) { return j * n - (j * (j - 1)) / 2 + (i - j); }  // i >= j
+
+__global__ void __launch_bounds__(1024) chol_f64_kernel(const double* __restrict__ G, long g_batch_stride, int n,
+                                                        double* __restrict__ Lout, long l_batch_stride) {
+    extern __shared__ __attribute__((aligned(16))) double a[];  // packed lower, column-major; then n col buffer
+    double* col = a + (size_t)n * (n + 1) / 2;
+    __shared__ double sh_piv;
+    __shared__ double red[32];
+    const int m = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    const double* Gm = G + (long)m * g_batch_stride;
+    double dmax = 0.;
+    for (int j = wave; j < n; j += nw)
+        for (int i = j + lane; i < n; i += 64) {
+            const double v = Gm[(long)i * n + j];
+            a[pk(i, j, n)] = v;
+            if (i == j) dmax = fmax(dmax, v);
+        }
+    // block max of the diagonal
+    for (int s = 32; s > 0; s >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, s, 64));
+    if (lane == 0) red[wave] = dmax;
+    __syncthreads();
+    dmax = 0.;
+    for (int i = 0; i < nw; ++i) dmax = fmax(dmax, red[i]);
+    const double thr = dmax * (double)n * 1e-15;
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) {
+            const double d = a[pk(j, j, n)];
+            sh_piv = d > thr ? sqrt(d) : 0.;
+        }
+        __syncthreads();
+        const double piv = sh_piv;
+        const double inv = piv > 0. ? 1. / piv : 0.;
+        for (int i = j + tid; i < n; i += nthr) {
+            const double v = (i == j) ? piv : a[pk(i, j, n)] * inv;
+            a[pk(i, j, n)] = v;
+            col[i] = v;
+        }
+        __syncthreads();
+        if (piv > 0.) {
+            for (int k = j + 1 + wave; k < n; k += nw) {
+                const double ck = col[k];
+                for (int i = k + lane; i < n; i += 64) a[pk(i, k, n)] -= col[i] * ck;
+            }
+        }
+        // next iteration's first barrier orders these updates before the pivot read
+        __syncthreads();
+    }
+    double* Lm = Lout + (long)m * l_batch_stride;
+    for (int idx = tid; idx < n * n; idx += nthr) {
+        const int i = idx / n, j = idx - i * n;
+        Lm[idx] = i >= j ? a[pk(i, j, n)] : 0.;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// W[b] = [ L_a^T L_b ; L_b ]   (2n x n, column-major fp32, leading dimension 2n)
+// grid = (ceil(n*n/256), batch), block = 256.  fp64 accumulate.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stack_product_kernel(const double* __restrict__ La,
+                                                            const double* __restrict__ Lb, long l_batch_stride,
+                                                            int n, float* __restrict__ W, long w_batch_stride) {
+    const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;   // consecutive threads: consecutive j
+    const double* A = La + (long)b * l_batch_stride;
+    const double* B = Lb + (long)b * l_batch_stride;
+    double acc = 0.;
+    for (int k = (i > j ? i : j); k < n; ++k) acc = fma(A[(long)k * n + i], B[(long)k * n + j], acc);
+    float* Wb = W + (long)b * w_batch_stride;
+    Wb[(long)j * 2 * n + i] = (float)acc;
+    Wb[(long)j * 2 * n + n + i] = (float)B[(long)i * n + j];
+}
+
+// ---------------------------------------------------------------------------
+// Finalize: nuclear norm, teacher trace, per-sample loss, and K' = Y Sigma^+ Y^T.
+// grid = batch, block = 256.  W is the rotated stack (top: U Sigma, bottom: Y = L_b V).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) procrustes_finalize_kernel(
+    const float* __restrict__ W, long w_batch_stride, const float* __restrict__ sigma, int n, int n_s,
+    const double* __restrict__ Gb, long g_batch_stride, const float* __restrict__ omega,
+    const int* __restrict__ tap0, const int* __restrict__ tap1, const float* __restrict__ lam,
+    const float* __restrict__ tr_s, float* __restrict__ tr_t_out, float* __restrict__ nuc_out,
+    float* __restrict__ loss_out, float* __restrict__ Kp) {
+    extern __shared__ float sm[];
+    float* isig = sm;                      // n : 1/sigma_j or 0 when truncated
+    __shared__ float red[32];
+    __shared__ double redd[32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* sg = sigma + (long)b * n;
+    float smax = 0.f, ssum = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        smax = fmaxf(smax, sg[j]);
+        ssum += sg[j];
+    }
+    smax = wave_max(smax);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = smax;
+    __syncthreads();
+    smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float nuc = block_sum(ssum, red);
+    const float thr = smax * (float)n * 1.1920929e-7f;
+    for (int j = tid; j < n; j += 256) isig[j] = sg[j] > thr ? 1.f / sg[j] : 0.f;
+    // teacher trace on the student grid: sum_n w_n |sum_j I[n,j] tc_j|^2, from the fp64 Gram
+    const double* G = Gb + (long)b * g_batch_stride;
+    double part = 0.;
+    for (int s = tid; s < n_s; s += 256) {
+        const double w = (double)omega[(long)b * n_s + s];
+        if (tap0) {
+            const int i0 = tap0[s], i1 = tap1[s];
+            const double l1 = (double)lam[s], l0 = 1. - l1;
+            part += w * (l0 * l0 * G[(long)i0 * n + i0] + 2. * l0 * l1 * G[(long)i0 * n + i1] + l1 * l1 * G[(long)i1 * n + i1]);
+        } else {
+            part += w * G[(long)s * n + s];
+        }
+    }
+    const double trt = block_sum(part, redd);
+    if (tid == 0) {
+        tr_t_out[b] = (float)trt;
+        nuc_out[b] = nuc;
+        loss_out[b] = tr_s[b] + (float)trt - 2.f * nuc;
+    }
+    __syncthreads();
+    if (Kp) {
+        // Yh = Y diag(sigma^-1/2) staged in LDS (column-major like W), K' = Yh Yh^T
+        const float* Wb = W + (long)b * w_batch_stride;
+        float* Yh = sm + n;
+        for (int idx = tid; idx < n * n; idx += 256) {
+            const int j = idx / n, r = idx - j * n;
+            Yh[idx] = Wb[(long)j * 2 * n + n + r] * sqrtf(isig[j]);
+        }
+        __syncthreads();
+        float* K = Kp + (long)b * n * n;
+        for (int idx = tid; idx < n * n; idx += 256) {
+            const int r = idx / n, c = idx - r * n;
+            float acc = 0.f;
+            for (int j = 0; j < n; ++j) acc = fmaf(Yh[j * n + r], Yh[j * n + c], acc);
+            K[idx] = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Backward, student tokens:  dX[b,s,:] = coef * w_s * ( (x_s - mu) - interp(H)[s] ),
+//   H = K' A' (n_t x D),  coef = *scale_ptr * scale_const.     grid = (n_s, B), block = 128
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(128) student_grad_kernel(const T* __restrict__ X, long sb, long sn, int n_s, int n_t,
+                                                           int D, const float* __restrict__ omega,
+                                                           const float* __restrict__ mu, const float* __restrict__ H,
+                                                           const int* __restrict__ tap0, const int* __restrict__ tap1,
+                                                           const float* __restrict__ lam,
+                                                           const float* __restrict__ scale_ptr, float scale_const,
+                                                           float* __restrict__ dX) {
+    const int s = blockIdx.x, b = blockIdx.y;
+    const float coef = scale_ptr[0] * scale_const * omega[(long)b * n_s + s];
+    const T* x = X + (long)b * sb + (long)s * sn;
+    const float* m = mu + (long)b * D;
+    int i0 = s, i1 = s;
+    float l1 = 0.f;
+    if (tap0) {
+        i0 = tap0[s];
+        i1 = tap1[s];
+        l1 = lam[s];
+    }
+    const float* h0 = H + ((long)b * n_t + i0) * D;
+    const float* h1 = H + ((long)b * n_t + i1) * D;
+    float* out = dX + ((long)b * n_s + s) * D;
+    for (int d = threadIdx.x; d < D; d += 128) {
+        const float tgt = (1.f - l1) * h0[d] + l1 * h1[d];
+        out[d] = coef * ((to_f32(x[d]) - m[d]) - tgt);
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Stand-alone token-count interpolation (reference combined.py:9-14), used by the public
+// `_align_token_count`; the fused loss path never materialises this tensor.
+// grid = (n_out, B), block = 128.   adjoint != 0: scatter-free transpose (out is n_in rows).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(128) resample_tokens_kernel(const T* __restrict__ X, long sb, long sn, long sd,
+                                                              int n_in, int n_out, int D,
+                                                              const int* __restrict__ tap0,
+                                                              const int* __restrict__ tap1,
+                                                              const float* __restrict__ lam, float* __restrict__ out) {
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int i0 = tap0[s], i1 = tap1[s];
+    const float l1 = lam[s], l0 = 1.f - l1;
+    const T* x0 = X + (long)b * sb + (long)i0 * sn;
+    const T* x1 = X + (long)b * sb + (long)i1 * sn;
+    float* o = out + ((long)b * n_out + s) * D;
+    for (int d = threadIdx.x; d < D; d += 128) o[d] = l0 * to_f32(x0[(long)d * sd]) + l1 * to_f32(x1[(long)d * sd]);
+}
+
+// adjoint: dX[b, j, :] = sum_{s in [range0[j], range1[j])} I[s, j] dY[b, s, :]
+__global__ void __launch_bounds__(128) resample_tokens_adjoint_kernel(const float* __restrict__ dY, int n_in,
+                                                                      int n_out, int D,
+                                                                      const int* __restrict__ tap0,
+                                                                      const int* __restrict__ tap1,
+                                                                      const float* __restrict__ lam,
+                                                                      const int* __restrict__ range0,
+                                                                      const int* __restrict__ range1,
+                                                                      float* __restrict__ dX) {
+    const int j = blockIdx.x, b = blockIdx.y;
+    const int s0 = range0[j], s1 = range1[j];
+    for (int d = threadIdx.x; d < D; d += 128) {
+        float acc = 0.f;
+        for (int s = s0; s < s1; ++s) {
+            const float l1 = lam[s];
+            const float coef = (tap0[s] == j ? 1.f - l1 : 0.f) + (tap1[s] == j ? l1 : 0.f);
+            acc = fmaf(coef, dY[((long)b * n_out + s) * D + d], acc);
+        }
+        dX[((long)b * n_in + j) * D + d] = acc;
+    }
+}
+
+}  // namespace basd
+
+using namespace basd;
+
+extern "C" {
+
+// relational.py:22-34 on the layer-mixed attention.  attn_ptrs: device array of L pointers.
+int basd_token_weights(const void* const* attn_ptrs, int dtype, const float* mix, int L, long sb, long sh, long sq,
+                       long sk, int B, int H, int A, int has_cls, int n_a, int n_t, int n_s, const int* atap0,
+                       const int* atap1, const float* alam, const int* tap0, const int* tap1, const float* lam,
+                       float* omega, float* omega_t, float* raw_out, hipStream_t stream) {
+    BASD_CHECK_ARG(attn_ptrs && mix && omega && omega_t && L > 0 && B > 0 && H > 0 && n_a > 0 && n_t > 0 && n_s > 0);
+    BASD_CHECK_ARG(A == n_a + (has_cls ? 1 : 0));
+    BASD_CHECK_ARG((n_a == n_s) == (atap0 == nullptr));
+    BASD_CHECK_ARG((n_t == n_s) == (tap0 == nullptr));
+    const size_t lds = sizeof(float) * (size_t)(n_a + n_s);
+    if (dtype == BASD_DTYPE_F32)
+        token_weights_kernel<float><<<B, 256, lds, stream>>>(attn_ptrs, mix, L, sb, sh, sq, sk, H, A, has_cls, n_a, n_t, n_s, atap0, atap1, alam, tap0, tap1, lam, omega, omega_t, raw_out);
+    else if (dtype == BASD_DTYPE_BF16)
+        token_weights_kernel<__hip_bfloat16><<<B, 256, lds, stream>>>(attn_ptrs, mix, L, sb, sh, sq, sk, H, A, has_cls, n_a, n_t, n_s, atap0, atap1, alam, tap0, tap1, lam, omega, omega_t, raw_out);
+    else
+        return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+// relational.py:36-45 (student half) + the transpose of combined.py:9-14.
+int basd_student_project(const void* x, int dtype, long sb, long sn, int B, int n_s, int n_t, int D,
+                         const float* omega, const int* tap0, const int* tap1, const float* lam, const int* range0,
+                         const int* range1, float* mu, float* tr_s, float* a_prime, hipStream_t stream) {
+    BASD_CHECK_ARG(x && omega && mu && tr_s && a_prime && B > 0 && n_s > 0 && n_t > 0 && D > 0);
+    BASD_CHECK_ARG((n_t == n_s) == (tap0 == nullptr));
+    const size_t lds = sizeof(float) * (size_t)(D + n_s);
+    if (dtype == BASD_DTYPE_F32)
+        student_project_kernel<float><<<B, 256, lds, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+    else if (dtype == BASD_DTYPE_BF16)
+        student_project_kernel<__hip_bfloat16><<<B, 256, lds, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+    else
+        return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+// layer_selector.py:110-111 (token mixing) + relational.py:37,39 (teacher centring) on the teacher grid.
+int basd_teacher_center(const void* const* tok_ptrs, int dtype, const float* mix, int L, long sb, long sn, long sd,
+                        int B, int n_t, int D, const float* omega_t, float* mu, float* tc, hipStream_t stream) {
+    BASD_CHECK_ARG(tok_ptrs && mix && omega_t && mu && tc && L > 0 && B > 0 && n_t > 0 && D > 0);
+    const size_t lds = sizeof(float) * ((size_t)n_t * 65 + n_t + 64);
+    if (lds > 150 * 1024) return BASD_EUNSUPPORTED;
+    const dim3 grid((D + 63) / 64, B);
+    if (dtype == BASD_DTYPE_F32) {
+        (void)hipFuncSetAttribute((const void*)teacher_center_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        teacher_center_kernel<float><<<grid, 256, lds, stream>>>(tok_ptrs, mix, L, sb, sn, sd, n_t, D, omega_t, mu, tc);
+    } else if (dtype == BASD_DTYPE_BF16) {
+        (void)hipFuncSetAttribute((const void*)teacher_center_kernel<__hip_bfloat16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        teacher_center_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>(tok_ptrs, mix, L, sb, sn, sd, n_t, D, omega_t, mu, tc);
+    } else {
+        return BASD_EINVAL;
+    }
+    BASD_RETURN_LAST();
+}
+
+// G[b] = P[b] P[b]^T in fp64 (the bmm of relational.py:47 reduced to the teacher grid).
+int basd_gram_f64(const float* p, long p_batch_stride, int n, int D, int batch, double* g, long g_batch_stride,
+                  hipStream_t stream) {
+    BASD_CHECK_ARG(p && g && n > 0 && D > 0 && batch > 0);
+    BASD_CHECK_ARG(((uintptr_t)p & 15) == 0 && D % 4 == 0 && p_batch_stride % 4 == 0);
+    const int nt = (n + 15) / 16, ntiles = nt * (nt + 1) / 2;
+    int waves = (ntiles + G64_TPW - 1) / G64_TPW;
+    if (waves < 4) waves = ntiles < 4 ? ntiles : 4;
+    if (waves > 16) return BASD_EUNSUPPORTED;   // n > 240
+    const size_t lds = sizeof(float) * (size_t)nt * 16 * G64_LD;
+    gram_f64_kernel<<<batch, 64 * waves, lds, stream>>>(p, p_batch_stride, n, D, g, g_batch_stride);
+    BASD_RETURN_LAST();
+}
+
+int basd_chol_f64(const double* g, long g_batch_stride, int n, int batch, double* l, long l_batch_stride,
+                  hipStream_t stream) {
+    BASD_CHECK_ARG(g && l && n > 0 && batch > 0);
+    const size_t lds = sizeof(double) * ((size_t)n * (n + 1) / 2 + n);
+    if (lds > 158 * 1024) return BASD_EUNSUPPORTED;
+    (void)hipFuncSetAttribute((const void*)chol_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+    const int threads = n >= 128 ? 1024 : n >= 64 ? 512 : 256;
+    chol_f64_kernel<<<batch, threads, lds, stream>>>(g, g_batch_stride, n, l, l_batch_stride);
+    BASD_RETURN_LAST();
+}
+
+int basd_stack_product(const double* la, const double* lb, long l_batch_stride, int n, int batch, float* w,
+                       long w_batch_stride, hipStream_t stream) {
+    BASD_CHECK_ARG(la && lb && w && n > 0 && batch > 0);
+    stack_product_kernel<<<dim3((n * n + 255) / 256, batch), 256, 0, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride);
+    BASD_RETURN_LAST();
+}
+
+// relational.py:45-50 per sample: tr_t, nuclear norm, loss_b = tr_s + tr_t - 2 nuc; K' for backward (nullable).
+int basd_procrustes_finalize(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
+                             const double* gb, long g_batch_stride, const float* omega, const int* tap0,
+                             const int* tap1, const float* lam, const float* tr_s, float* tr_t, float* nuc,
+                             float* loss, float* k_prime, hipStream_t stream) {
+    BASD_CHECK_ARG(w && sigma && gb && omega && tr_s && tr_t && nuc && loss && n > 0 && batch > 0);
+    const size_t lds = sizeof(float) * ((size_t)n + (k_prime ? (size_t)n * n : 0));
+    if (lds > 156 * 1024) return BASD_EUNSUPPORTED;
+    (void)hipFuncSetAttribute((const void*)procrustes_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    procrustes_finalize_kernel<<<batch, 256, lds, stream>>>(w, w_batch_stride, sigma, n, n_s, gb, g_batch_stride, omega, tap0, tap1, lam, tr_s, tr_t, nuc, loss, k_prime);
+    BASD_RETURN_LAST();
+}
+
+// Gradient of sum_b coef * loss_b with respect to the student tokens (autograd of relational.py:36-50).
+int basd_student_grad(const void* x, int dtype, long sb, long sn, int B, int n_s, int n_t, int D, const float* omega,
+                      const float* mu, const float* h, const int* tap0, const int* tap1, const float* lam,
+                      const float* scale_ptr, float scale_const, float* dx, hipStream_t stream) {
+    BASD_CHECK_ARG(x && omega && mu && h && scale_ptr && dx && B > 0 && n_s > 0 && n_t > 0 && D > 0);
+    const dim3 grid(n_s, B);
+    if (dtype == BASD_DTYPE_F32)
+        student_grad_kernel<float><<<grid, 128, 0, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx);
+    else if (dtype == BASD_DTYPE_BF16)
+        student_grad_kernel<__hip_bfloat16><<<grid, 128, 0, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx);
+    else
+        return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+// combined.py:9-14 as a stand-alone op: out (B, n_out, D) fp32 contiguous.
+int basd_resample_tokens(const void* x, int dtype, long sb, long sn, long sd, int B, int n_in, int n_out, int D,
+                         const int* tap0, const int* tap1, const float* lam, float* out, hipStream_t stream) {
+    BASD_CHECK_ARG(x && tap0 && tap1 && lam && out && B > 0 && n_in > 0 && n_out > 0 && D > 0);
+    const dim3 grid(n_out, B);
+    if (dtype == BASD_DTYPE_F32)
+        resample_tokens_kernel<float><<<grid, 128, 0, stream>>>((const float*)x, sb, sn, sd, n_in, n_out, D, tap0, tap1, lam, out);
+    else if (dtype == BASD_DTYPE_BF16)
+        resample_tokens_kernel<__hip_bfloat16><<<grid, 128, 0, stream>>>((const __hip_bfloat16*)x, sb, sn, sd, n_in, n_out, D, tap0, tap1, lam, out);
+    else
+        return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+// Adjoint of basd_resample_tokens: dx (B, n_in, D) from dy (B, n_out, D), both fp32 contiguous.
+int basd_resample_tokens_adjoint(const float* dy, int B, int n_in, int n_out, int D, const int* tap0,
+                                 const int* tap1, const float* lam, const int* range0, const int* range1, float* dx,
+                                 hipStream_t stream) {
+    BASD_CHECK_ARG(dy && tap0 && tap1 && lam && range0 && range1 && dx && B > 0 && n_in > 0 && n_out > 0 && D > 0);
+    resample_tokens_adjoint_kernel<<<dim3(n_in, B), 128, 0, stream>>>(dy, n_in, n_out, D, tap0, tap1, lam, range0, range1, dx);
+    BASD_RETURN_LAST();
+}
+
+}  // extern "C"
