@@ -114,10 +114,12 @@ int basd_student_project(const void* x, int dtype, long sb, long sn, int B, int 
                          const float* omega, const int* tap0, const int* tap1, const float* lam, const int* range0,
                          const int* range1, float* mu, float* tr_s, float* a_prime, hipStream_t stream);
 
-/* Teacher half: soft layer mixing (layer_selector.py:110-111) + weighted centring (relational.py:37,39)
- * on the teacher's own token grid.  tok_ptrs: device array of L pointers sharing strides. */
+/* Teacher half: soft layer mixing (layer_selector.py:110-111), optional resampling to the core grid of
+ * n tokens (combined.py:9-14, only when the teacher grid is finer than the student's; g0/g1/glam gather
+ * taps, else NULL) and weighted centring (relational.py:37,39).  tok_ptrs: device array of L pointers. */
 int basd_teacher_center(const void* const* tok_ptrs, int dtype, const float* mix, int L, long sb, long sn, long sd,
-                        int B, int n_t, int D, const float* omega_t, float* mu, float* tc, hipStream_t stream);
+                        int B, int n, int D, const int* g0, const int* g1, const float* glam, const float* omega_t,
+                        float* mu, float* tc, hipStream_t stream);
 
 /* G[b] = P[b] P[b]^T accumulated in fp64 on v_mfma_f64_16x16x4_f64 (the bmm of relational.py:47,
  * reduced to the teacher grid). */

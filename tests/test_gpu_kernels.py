@@ -148,4 +148,4 @@ def test_resample_matches_interpolate(dev):
         gy = torch.randn(y.shape, generator=g).to(dev)
         y.backward(gy)
         ref.backward(gy)
-        assert (x.grad - ref_in.grad).abs().max() < 2e-6
+        assert (x.grad - ref_in.grad).abs().max() < 1e-6 * ref_in.grad.abs().max()

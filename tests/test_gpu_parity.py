@@ -80,7 +80,8 @@ def test_relational_golden(golden, tag):
 
 
 @pytest.mark.parametrize("n_s,n_t,d_s,d_t,cls", [(196, 49, 384, 2048, False), (64, 64, 192, 256, True),
-                                                  (36, 9, 64, 160, False), (64, 1, 192, 512, False)])
+                                                  (36, 9, 64, 160, False), (64, 1, 192, 512, False),
+                                                  (49, 64, 96, 128, True), (196, 256, 64, 96, False)])
 def test_procrustes_terms_vs_oracle(n_s, n_t, d_s, d_t, cls):
     """tr_s, tr_t, nuc per sample against the oracle's LAPACK path, including the interpolated grids."""
     from basd_amd import ops
@@ -98,7 +99,9 @@ def test_procrustes_terms_vs_oracle(n_s, n_t, d_s, d_t, cls):
     np.testing.assert_allclose(pc.omega[0].cpu().numpy(), w.numpy(), rtol=2e-6, atol=1e-9)
     np.testing.assert_allclose(pc.tr_s[0].cpu().numpy(), tr_s.numpy(), rtol=1e-5)
     np.testing.assert_allclose(pc.tr_t[0].cpu().numpy(), tr_t.numpy(), rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(pc.nuc[0].cpu().numpy(), nuc.numpy(), rtol=2e-5, atol=1e-5)
+    # atol: with a single teacher token the centred teacher is exactly 0 here, while the oracle's fp32
+    # centring leaves ~1e-5 of round-off in its nuclear norm
+    np.testing.assert_allclose(pc.nuc[0].cpu().numpy(), nuc.numpy(), rtol=2e-5, atol=2e-6 * float((tr_s + tr_t).max()))
     ref_loss = (tr_s + tr_t - 2 * nuc).numpy()
     np.testing.assert_allclose(pc.loss_b[0].cpu().numpy(), ref_loss, rtol=1e-4)
 

@@ -31,7 +31,7 @@ SIGNATURES = {
     "basd_token_weights": [vp, i32, vp, i32, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp,
                            vp, vp, vp, vp, vp, vp],
     "basd_student_project": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "basd_teacher_center": [vp, i32, vp, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp],
+    "basd_teacher_center": [vp, i32, vp, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_gram_f64": [vp, i64, i32, i32, i32, vp, i64, vp],
     "basd_chol_f64": [vp, i64, i32, i32, vp, i64, vp],
     "basd_stack_product": [vp, vp, i64, i32, i32, vp, i64, vp],

@@ -270,12 +270,15 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     _, n_t, d_t = teachers[0].shape
     H, A = attns[0].shape[1], attns[0].shape[2]
     n_a = A - (1 if has_cls else 0)
-    if n_t > n_s:
-        raise NotImplementedError("teacher grids finer than the student grid (N_t > N_s) are not supported yet")
-    n = n_t
-    tp = taps(n_t, n_s, dev)
+    # Core grid: the coarser of the two token grids.  A coarser teacher (CNN feature maps) keeps its own
+    # grid and the interpolation is applied, transposed, to the student side; a finer teacher is resampled
+    # to the student grid while it is being mixed / centred.
+    n = min(n_s, n_t)
+    tp = taps(n_t, n_s, dev) if n_t < n_s else None                      # student-side (transposed) taps
+    gt = taps(n_t, n_s, dev) if n_t > n_s else None                      # teacher-side gather taps
     t0, t1, lam = (tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr()) if tp else (None, None, None)
     r0, r1 = (tp.range0.data_ptr(), tp.range1.data_ptr()) if tp else (None, None)
+    g0, g1, glam = (gt.tap0.data_ptr(), gt.tap1.data_ptr(), gt.lam.data_ptr()) if gt else (None, None, None)
     atp = taps(n_a, n_s, dev)
     a0, a1, alam = (atp.tap0.data_ptr(), atp.tap1.data_ptr(), atp.lam.data_ptr()) if atp else (None, None, None)
     st = _stream()
@@ -285,22 +288,22 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     tok_tab, att_tab = _ptr_table(teachers), _ptr_table(attns)
     f32 = dict(device=dev, dtype=torch.float32)
     omega = torch.empty((G, B, n_s), **f32)
-    omega_t = torch.empty((G, B, n_t), **f32)
+    omega_t = torch.empty((G, B, n), **f32)
     mu_t = torch.empty((G, B, d_t), **f32)
     tc = torch.empty((G, B, n, d_t), **f32)
     sb, sh, sq, sk = attns[0].stride()
     tsb, tsn, tsd = teachers[0].stride()
     for g in range(G):
         _lib.call("basd_token_weights", att_tab.data_ptr(), _dtype_code(attns[0]), mix[g].data_ptr(), L, sb, sh, sq,
-                  sk, B, H, A, int(has_cls), n_a, n_t, n_s, a0, a1, alam, t0, t1, lam, omega[g].data_ptr(),
+                  sk, B, H, A, int(has_cls), n_a, n, n_s, a0, a1, alam, t0, t1, lam, omega[g].data_ptr(),
                   omega_t[g].data_ptr(), None, st)
         _lib.call("basd_teacher_center", tok_tab.data_ptr(), _dtype_code(teachers[0]), mix[g].data_ptr(), L, tsb,
-                  tsn, tsd, B, n_t, d_t, omega_t[g].data_ptr(), mu_t[g].data_ptr(), tc[g].data_ptr(), st)
+                  tsn, tsd, B, n, d_t, g0, g1, glam, omega_t[g].data_ptr(), mu_t[g].data_ptr(), tc[g].data_ptr(), st)
     mu_s = torch.empty((E, B, d_s), **f32)
     tr_s = torch.empty((E, B), **f32)
     a_prime = torch.empty((E, B, n, d_s), **f32)
     for e, x in enumerate(students):
-        _lib.call("basd_student_project", x.data_ptr(), _dtype_code(x), x.stride(0), x.stride(1), B, n_s, n_t, d_s,
+        _lib.call("basd_student_project", x.data_ptr(), _dtype_code(x), x.stride(0), x.stride(1), B, n_s, n, d_s,
                   omega[0 if shared else e].data_ptr(), t0, t1, lam, r0, r1, mu_s[e].data_ptr(), tr_s[e].data_ptr(),
                   a_prime[e].data_ptr(), st)
     # fp64 Grams on the teacher grid, Cholesky factors, stacked product

@@ -171,52 +171,65 @@ __global__ void __launch_bounds__(256) student_project_kernel(const T* __restric
 }
 
 // ---------------------------------------------------------------------------
-// Teacher side: mix the L layers, weighted-centre on the teacher grid.
-//   Tc[b, j, :] = sum_l mix_l T_l[b, j, :] - sum_j' omega_t[j'] (sum_l mix_l T_l[b, j', :])
-// grid = (ceil(D/64), B), block = 256.  Handles feature-contiguous (sd == 1) and
-// channel-major (sn == 1) teachers through an LDS tile of 64 features x n_t tokens.
+// Teacher side: mix the L layers, (optionally) resample to the core grid, weighted-centre.
+//   Tbar[b, r, :] = sum_l mix_l T_l[b, r, :]                               (layer_selector.py:110-111)
+//   That[b, j, :] = (1-lam_j) Tbar[b, g0_j, :] + lam_j Tbar[b, g1_j, :]    (combined.py:9-14; only when the
+//                   teacher grid is FINER than the student grid -- otherwise the interpolation is folded
+//                   into the student side and That = Tbar)
+//   Tc[b, j, :]   = That[b, j, :] - sum_j' omega_t[j'] That[b, j', :]      (relational.py:37,39)
+// grid = (ceil(D/64), B), block = 256.  Handles feature-contiguous (sd == 1) and channel-major
+// (sn == 1) teachers through an LDS tile of 64 features x n tokens.
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) teacher_center_kernel(const void* const* __restrict__ tok_ptrs,
                                                              const float* __restrict__ mix, int L, long sb, long sn,
-                                                             long sd, int n_t, int D,
+                                                             long sd, int n, int D, const int* __restrict__ g0,
+                                                             const int* __restrict__ g1,
+                                                             const float* __restrict__ glam,
                                                              const float* __restrict__ omega_t,
                                                              float* __restrict__ mu_out, float* __restrict__ Tc) {
     extern __shared__ float sm[];
-    float* tile = sm;                    // n_t x 65
-    float* wt = sm + (size_t)n_t * 65;   // n_t
-    float* mu = wt + n_t;                // 64
+    float* tile = sm;                  // n x 65
+    float* wt = sm + (size_t)n * 65;   // n
+    float* mu = wt + n;                // 64
     const int b = blockIdx.y, d0 = blockIdx.x * 64, tid = threadIdx.x;
-    for (int j = tid; j < n_t; j += 256) wt[j] = omega_t[(long)b * n_t + j];
-    const int total = n_t * 64;
-    if (sd == 1) {
-        for (int idx = tid; idx < total; idx += 256) {
-            const int j = idx >> 6, dd = idx & 63, d = d0 + dd;
-            float acc = 0.f;
-            if (d < D)
+    for (int j = tid; j < n; j += 256) wt[j] = omega_t[(long)b * n + j];
+    const int total = n * 64;
+    const bool feat_fast = sd == 1;
+    for (int idx = tid; idx < total; idx += 256) {
+        int j, dd;
+        if (feat_fast) { j = idx >> 6; dd = idx & 63; }
+        else { dd = idx / n; j = idx - dd * n; }
+        const int d = d0 + dd;
+        float v = 0.f;
+        if (d < D) {
+            const long off = b * sb + (long)d * sd;
+            if (g0) {
+                const long r0 = g0[j], r1 = g1[j];
+                float a0 = 0.f, a1 = 0.f;
+                for (int l = 0; l < L; ++l) {
+                    const T* p = (const T*)tok_ptrs[l];
+                    a0 = fmaf(mix[l], to_f32(p[off + r0 * sn]), a0);
+                    a1 = fmaf(mix[l], to_f32(p[off + r1 * sn]), a1);
+                }
+                const float l1 = glam[j];
+                v = (1.f - l1) * a0 + l1 * a1;
+            } else {
                 for (int l = 0; l < L; ++l)
-                    acc = fmaf(mix[l], to_f32(((const T*)tok_ptrs[l])[b * sb + (long)j * sn + d]), acc);
-            tile[j * 65 + dd] = acc;
+                    v = fmaf(mix[l], to_f32(((const T*)tok_ptrs[l])[off + (long)j * sn]), v);
+            }
         }
-    } else {
-        for (int idx = tid; idx < total; idx += 256) {
-            const int dd = idx / n_t, j = idx - dd * n_t, d = d0 + dd;
-            float acc = 0.f;
-            if (d < D)
-                for (int l = 0; l < L; ++l)
-                    acc = fmaf(mix[l], to_f32(((const T*)tok_ptrs[l])[b * sb + (long)j * sn + (long)d * sd]), acc);
-            tile[j * 65 + dd] = acc;
-        }
+        tile[j * 65 + dd] = v;
     }
     __syncthreads();
     if (tid < 64) {
         float acc = 0.f;
-        for (int j = 0; j < n_t; ++j) acc = fmaf(wt[j], tile[j * 65 + tid], acc);
+        for (int j = 0; j < n; ++j) acc = fmaf(wt[j], tile[j * 65 + tid], acc);
         mu[tid] = acc;
         if (d0 + tid < D) mu_out[(long)b * D + d0 + tid] = acc;
     }
     __syncthreads();
-    float* out = Tc + (long)b * n_t * D;
+    float* out = Tc + (long)b * n * D;
     for (int idx = tid; idx < total; idx += 256) {
         const int j = idx >> 6, dd = idx & 63, d = d0 + dd;
         if (d < D) out[(long)j * D + d] = tile[j * 65 + dd] - mu[dd];
@@ -569,19 +582,22 @@ int basd_student_project(const void* x, int dtype, long sb, long sn, int B, int 
     BASD_RETURN_LAST();
 }
 
-// layer_selector.py:110-111 (token mixing) + relational.py:37,39 (teacher centring) on the teacher grid.
+// layer_selector.py:110-111 (token mixing) + relational.py:37,39 (teacher centring) on the core grid of n tokens.
+// g0/g1/glam (nullable): gather taps when the teacher grid (finer than the student's) is resampled first.
 int basd_teacher_center(const void* const* tok_ptrs, int dtype, const float* mix, int L, long sb, long sn, long sd,
-                        int B, int n_t, int D, const float* omega_t, float* mu, float* tc, hipStream_t stream) {
-    BASD_CHECK_ARG(tok_ptrs && mix && omega_t && mu && tc && L > 0 && B > 0 && n_t > 0 && D > 0);
-    const size_t lds = sizeof(float) * ((size_t)n_t * 65 + n_t + 64);
+                        int B, int n, int D, const int* g0, const int* g1, const float* glam, const float* omega_t,
+                        float* mu, float* tc, hipStream_t stream) {
+    BASD_CHECK_ARG(tok_ptrs && mix && omega_t && mu && tc && L > 0 && B > 0 && n > 0 && D > 0);
+    BASD_CHECK_ARG((g0 == nullptr) == (g1 == nullptr) && (g0 == nullptr) == (glam == nullptr));
+    const size_t lds = sizeof(float) * ((size_t)n * 65 + n + 64);
     if (lds > 150 * 1024) return BASD_EUNSUPPORTED;
     const dim3 grid((D + 63) / 64, B);
     if (dtype == BASD_DTYPE_F32) {
         (void)hipFuncSetAttribute((const void*)teacher_center_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        teacher_center_kernel<float><<<grid, 256, lds, stream>>>(tok_ptrs, mix, L, sb, sn, sd, n_t, D, omega_t, mu, tc);
+        teacher_center_kernel<float><<<grid, 256, lds, stream>>>(tok_ptrs, mix, L, sb, sn, sd, n, D, g0, g1, glam, omega_t, mu, tc);
     } else if (dtype == BASD_DTYPE_BF16) {
         (void)hipFuncSetAttribute((const void*)teacher_center_kernel<__hip_bfloat16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        teacher_center_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>(tok_ptrs, mix, L, sb, sn, sd, n_t, D, omega_t, mu, tc);
+        teacher_center_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>(tok_ptrs, mix, L, sb, sn, sd, n, D, g0, g1, glam, omega_t, mu, tc);
     } else {
         return BASD_EINVAL;
     }
