@@ -109,7 +109,8 @@ int basd_token_weights(const void* const* attn_ptrs, int dtype, const float* mix
                        float* omega, float* omega_t, float* raw_out, hipStream_t stream);
 
 /* Student half of relational.py:36-45 and the adjoint of combined.py:9-14:
- * mu = sum_n w_n x_n, tr_s = sum_n w_n |x_n - mu|^2, A' = I_interp^T diag(w) (X - 1 mu^T). */
+ * mu = sum_n w_n x_n, tr_s = sum_n w_n |x_n - mu|^2 (as (B, ceil(D/64)) per-slab partials),
+ * A' = I_interp^T diag(w) (X - 1 mu^T). */
 int basd_student_project(const void* x, int dtype, long sb, long sn, int B, int n_s, int n_t, int D,
                          const float* omega, const int* tap0, const int* tap1, const float* lam, const int* range0,
                          const int* range1, float* mu, float* tr_s, float* a_prime, hipStream_t stream);
@@ -138,8 +139,8 @@ int basd_stack_product(const double* la, const double* lb, long l_batch_stride, 
  * and K' = Y Sigma^+ Y^T for the backward (nullable). */
 int basd_procrustes_finalize(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
                              const double* gb, long g_batch_stride, const float* omega, const int* tap0,
-                             const int* tap1, const float* lam, const float* tr_s, float* tr_t, float* nuc,
-                             float* loss, float* k_prime, hipStream_t stream);
+                             const int* tap1, const float* lam, const float* tr_s_part, int tr_slabs, float* tr_s,
+                             float* tr_t, float* nuc, float* loss, float* k_prime, hipStream_t stream);
 
 /* dX = (*scale_ptr * scale_const) * w_s * ((x_s - mu) - interp(K' A')[s]): autograd of relational.py:36-50
  * with respect to the student tokens. */

@@ -35,7 +35,8 @@ SIGNATURES = {
     "basd_gram_f64": [vp, i64, i32, i32, i32, vp, i64, vp],
     "basd_chol_f64": [vp, i64, i32, i32, vp, i64, vp],
     "basd_stack_product": [vp, vp, i64, i32, i32, vp, i64, vp],
-    "basd_procrustes_finalize": [vp, i64, vp, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "basd_procrustes_finalize": [vp, i64, vp, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp,
+                                 vp],
     "basd_resample_tokens": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "basd_resample_tokens_adjoint": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_student_grad": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp],
@@ -65,9 +66,24 @@ def load() -> C.CDLL:
     return _lib
 
 
+# Optional per-entry-point timing (bench.py): name -> list of (start_event, end_event) recorded on the
+# stream the kernels are queued on.  `timed_names` None = every entry point.
+timing: dict | None = None
+timed_names: set | None = None
+
+
 def call(name: str, *args) -> None:
     """Call an entry point that reports a status; non-zero becomes RuntimeError."""
-    status = getattr(load(), name)(*args)
+    if timing is not None and (timed_names is None or name in timed_names):
+        import torch
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        status = getattr(load(), name)(*args)
+        e1.record()
+        timing.setdefault(name, []).append((e0, e1))
+    else:
+        status = getattr(load(), name)(*args)
     if status != 0:
         kind = "invalid argument / unsupported shape" if status < 0 else "HIP error"
         raise RuntimeError(f"{name} failed with status {status} ({kind})")

@@ -174,12 +174,12 @@ class GrassmannianLayerSelector(nn.Module):
 
     # ---- teacher side: ranks + subspaces -------------------------------------------------
     @torch.no_grad()
-    def _teacher_spectra(self, teachers: list[torch.Tensor]):
-        """Per teacher layer: projected tokens -> uncentred Gram eigenvalues (for the MP rank) and the
-        centred Gram's eigen-decomposition (for the subspace).  Returns device ranks + solver state."""
+    def _teacher_grams(self, teachers: list[torch.Tensor]):
+        """Per teacher layer: projected tokens -> uncentred Gram / M (for the MP rank, layer_selector.py:12-15)
+        and centred Gram (for the subspace, :35)."""
         d_s = self.student_dim
         L = len(teachers)
-        B, n_t, d_t = teachers[0].shape
+        B, n_t, _ = teachers[0].shape
         M = B * n_t
         proj_t = self.proj_t.float().contiguous()
         n_u = d_s if M >= d_s else M
@@ -187,20 +187,19 @@ class GrassmannianLayerSelector(nn.Module):
         g_c = torch.empty((L, d_s, d_s), device=proj_t.device, dtype=torch.float32)
         for l, t in enumerate(teachers):
             z = ops.gemm_nt(ops.as_supported(t), proj_t)              # (M, d_s)  layer_selector.py:72 / :135
-            g_u[l] = _uncentred_gram(z)                               # layer_selector.py:12-15
+            g_u[l] = _uncentred_gram(z)
             mean = ops.colmean(z)
-            g_c[l] = ops.gemm_tn(z, z, mean_a=mean, mean_b=mean)      # centred z^T z  (:35)
-        vals_u, _, _, _ = ops.sym_eig(g_u)
-        ranks_dev = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
-        colnorm_c = ops.jacobi_onesided(g_c, d_s)
-        return ranks_dev, g_c, colnorm_c
+            g_c[l] = ops.gemm_tn(z, z, mean_a=mean, mean_b=mean)
+        return g_u, g_c, M
 
     @torch.no_grad()
     def _estimate_ranks(self, all_teacher_tokens: dict[int, torch.Tensor]) -> None:
         keys = list(all_teacher_tokens.keys())
         teachers = ops._check_common_layout([ops.as_supported(all_teacher_tokens[k]) for k in keys],
                                             "teacher token tensors")
-        ranks_dev, _, _ = self._teacher_spectra(teachers)
+        g_u, _, M = self._teacher_grams(teachers)
+        vals_u, _, _, _ = ops.sym_eig(g_u)
+        ranks_dev = ops.mp_rank_device(vals_u, M, self.student_dim, cap=self.student_dim - 1)   # :74
         for k, r in zip(keys, ranks_dev.tolist()):
             self.subspace_ranks[k] = int(r)
 
@@ -211,16 +210,27 @@ class GrassmannianLayerSelector(nn.Module):
             d_s = self.student_dim
             E, L = len(students), len(teachers)
             dev = students[0].device
-            ranks_dev, g_c, colnorm_c = self._teacher_spectra(teachers)
-            # student side is queued before the one host read-back of the step
-            s_gram = torch.empty((E, d_s, d_s), device=dev, dtype=torch.float32)
+            g_u, g_c, M = self._teacher_grams(teachers)
+            same = g_u.shape[1] == d_s
+            # every symmetric eigen-problem of the step goes through ONE solver call:
+            # [teacher uncentred (L) | teacher centred (L) | student centred (E)]
+            stack = torch.empty(((2 * L if same else L) + E, d_s, d_s), device=dev, dtype=torch.float32)
+            o_c = L if same else 0
+            if same:
+                stack[:L] = g_u
+            stack[o_c:o_c + L] = g_c
             for e, x in enumerate(students):
                 x = ops.as_supported(x)
                 mean = ops.colmean(x)
                 # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
                 # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
-                s_gram[e] = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
-            s_colnorm = ops.jacobi_onesided(s_gram, d_s)
+                stack[o_c + L + e] = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
+            colnorm = ops.jacobi_onesided(stack, d_s)
+            if same:
+                vals_u, _ = ops.sort_extract(stack[:L], colnorm[:L], 0)
+            else:
+                vals_u, _, _, _ = ops.sym_eig(g_u)
+            ranks_dev = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
             ranks = [int(r) for r in ranks_dev.tolist()]               # the step's single D2H sync
             for k, r in zip(keys, ranks):
                 self.subspace_ranks[k] = r
@@ -230,9 +240,9 @@ class GrassmannianLayerSelector(nn.Module):
                     "linalg.svd: The algorithm failed to converge because the input matrix contained "
                     "non-finite values (a teacher layer has Marchenko-Pastur rank 0).")
             kmax = max(ranks)
-            vals_c, u_t = ops.sort_extract(g_c, colnorm_c, kmax)       # (L, d_s), (L, kmax, d_s) rows = basis^T
+            vals_c, u_t = ops.sort_extract(stack[o_c:o_c + L], colnorm[o_c:o_c + L], kmax)   # (L, kmax, d_s)
             sw = ops.sqrt_clamp(vals_c[:, :kmax])                      # singular values S[:k]   (:36-37)
-            _, v_s = ops.sort_extract(s_gram, s_colnorm, kmax)         # (E, kmax, d_s) rows = Vt_s[:kmax]
+            _, v_s = ops.sort_extract(stack[o_c + L:], colnorm[o_c + L:], kmax)   # (E, kmax, d_s) = Vt_s[:kmax]
             proj_s_t = self.proj_s.float().t().contiguous()
             u_rot = ops.gemm_nt(u_t.view(L * kmax, d_s), proj_s_t).view(L, kmax, d_s)   # rows: (proj_s^T u)^T
             cos = torch.empty((E, L, kmax, kmax), device=dev, dtype=torch.float32)

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 
 F32, BF16 = 0, 1
-MAX_SWEEPS = 30
+MAX_SWEEPS = 20
 
 
 def _stream() -> int:
@@ -300,11 +300,13 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
         _lib.call("basd_teacher_center", tok_tab.data_ptr(), _dtype_code(teachers[0]), mix[g].data_ptr(), L, tsb,
                   tsn, tsd, B, n, d_t, g0, g1, glam, omega_t[g].data_ptr(), mu_t[g].data_ptr(), tc[g].data_ptr(), st)
     mu_s = torch.empty((E, B, d_s), **f32)
+    slabs = (d_s + 63) // 64
+    tr_part = torch.empty((E, B, slabs), **f32)
     tr_s = torch.empty((E, B), **f32)
     a_prime = torch.empty((E, B, n, d_s), **f32)
     for e, x in enumerate(students):
         _lib.call("basd_student_project", x.data_ptr(), _dtype_code(x), x.stride(0), x.stride(1), B, n_s, n, d_s,
-                  omega[0 if shared else e].data_ptr(), t0, t1, lam, r0, r1, mu_s[e].data_ptr(), tr_s[e].data_ptr(),
+                  omega[0 if shared else e].data_ptr(), t0, t1, lam, r0, r1, mu_s[e].data_ptr(), tr_part[e].data_ptr(),
                   a_prime[e].data_ptr(), st)
     # fp64 Grams on the teacher grid, Cholesky factors, stacked product
     g_all = torch.empty((E * B + G * B, n, n), device=dev, dtype=torch.float64)
@@ -330,8 +332,8 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     loss_b = torch.empty((E, B), **f32)
     k_prime = torch.empty((E, B, n, n), **f32) if need_backward else None
     _lib.call("basd_procrustes_finalize", W.data_ptr(), 2 * n * n, sigma.data_ptr(), n, n_s, E * B, g_b.data_ptr(),
-              n * n, omega_e.data_ptr(), t0, t1, lam, tr_s.data_ptr(), tr_t.data_ptr(), nuc.data_ptr(),
-              loss_b.data_ptr(), _ptr(k_prime), st)
+              n * n, omega_e.data_ptr(), t0, t1, lam, tr_part.data_ptr(), slabs, tr_s.data_ptr(), tr_t.data_ptr(),
+              nuc.data_ptr(), loss_b.data_ptr(), _ptr(k_prime), st)
     return ProcrustesContext(omega, mu_s, a_prime, k_prime, tr_s, tr_t, nuc, loss_b, sweeps)
 
 

@@ -14,10 +14,10 @@
 //             one 16-byte read feeds four k-steps (lane half h takes k = 8g+4h+s,
 //             the same permutation for A and B, so the sum over k is unchanged).
 //   gemm_tn : C[M,N] = A[K,M]^T * B[K,N]     contraction index is the slow one
-//             (Gram matrices over tokens).  LDS image [k][m], fragments by
-//             ds_read_b32 (lanes along m: conflict-free).  Optional per-column
-//             mean subtraction while staging, split over K with one slab per
-//             split (deterministic reduction by reduce_slabs_kernel).
+//             (Gram matrices over tokens).  LDS image [k/4][m][4] (4x4 register
+//             transposes while staging), fragments by ds_read_b128.  Optional
+//             per-column mean subtraction while staging, split over K with one
+//             slab per split (deterministic reduction by reduce_slabs_kernel).
 #include "basd_common.h"
 
 namespace basd {
@@ -177,46 +177,69 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand
 //   A: (Krows x M), B: (Krows x N); contraction over rows [k_begin, k_end) of the split.
 //   out: slab (split) or batch element: C + z * c_z_stride.
 // ---------------------------------------------------------------------------
-constexpr int TN_BK = 16, TN_LD = 128;
+constexpr int TN_BK = 32;
 
-template <typename T>
-__device__ __forceinline__ void tn_load(const GemmOperand& o, int krows_end, int cols, int k0, int col0, int tid,
-                                        const float* __restrict__ mean, float (&reg)[2][4]) {
+// Stage a (TN_BK rows x 128 columns) slab as [k/4][column][4]: one ds_read_b128 then yields the four
+// k-steps of a lane (lane half h takes k-group 2g + h; same permutation for A and B).  Threads 0..127 stage
+// A, 128..255 stage B; each thread transposes two 4x4 blocks in registers.
+template <typename T, bool VEC>
+__device__ __forceinline__ void tn_load(const GemmOperand& o, int krows_end, int cols, int k0, int col0, int t,
+                                        const float* __restrict__ mean, float (&reg)[2][4][4]) {
     const T* base = (const T*)o.ptr;
-    // f -> (k = f / 32, 4 consecutive columns): 32 lanes cover one 512-byte row segment
+    const int c = col0 + (t & 31) * 4;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int f = tid + 256 * j, k = k0 + (f >> 5), c = col0 + (f & 31) * 4;
-        if (k < krows_end) {
-            const T* p = base + row_off(o, k);
+        const int kg = (t >> 5) + 4 * j;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int cc = c + e;
-                reg[j][e] = cc < cols ? to_f32(p[(long)cc * o.sd]) - (mean ? mean[cc] : 0.f) : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const int k = k0 + kg * 4 + r;
+            if (k < krows_end) {
+                const T* p = base + row_off(o, k);
+                if (VEC && c + 3 < cols) {
+                    if (sizeof(T) == 4) {
+                        const float4 v = *(const float4*)(p + c);
+                        reg[j][r][0] = v.x; reg[j][r][1] = v.y; reg[j][r][2] = v.z; reg[j][r][3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) reg[j][r][e] = to_f32(p[c + e]);
+                    }
+                    if (mean) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) reg[j][r][e] -= mean[c + e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int cc = c + e;
+                        reg[j][r][e] = cc < cols ? to_f32(p[(long)cc * o.sd]) - (mean ? mean[cc] : 0.f) : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) reg[j][r][e] = 0.f;
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) reg[j][e] = 0.f;
         }
     }
 }
 
-__device__ __forceinline__ void tn_store_lds(float* __restrict__ tile, int tid, const float (&reg)[2][4]) {
+__device__ __forceinline__ void tn_store_lds(float* __restrict__ tile, int t, const float (&reg)[2][4][4]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int f = tid + 256 * j;
-        *(float4*)(tile + (f >> 5) * TN_LD + (f & 31) * 4) = make_float4(reg[j][0], reg[j][1], reg[j][2], reg[j][3]);
+        const int kg = (t >> 5) + 4 * j, m = (t & 31) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            *(float4*)(tile + ((kg * 128 + m + e) << 2)) = make_float4(reg[j][0][e], reg[j][1][e], reg[j][2][e], reg[j][3][e]);
     }
 }
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmOperand A, GemmOperand B, int M, int N, int Krows,
                                                       int splits, const float* __restrict__ mean_a,
                                                       const float* __restrict__ mean_b, float* __restrict__ C,
                                                       long ldc, long c_z_stride, float scale) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * TN_BK * TN_LD];
+    __shared__ __attribute__((aligned(16))) float lds[2 * TN_BK * 128];
     float* tA = lds;
-    float* tB = lds + TN_BK * TN_LD;
+    float* tB = lds + TN_BK * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int bz = blockIdx.z / splits, sp = blockIdx.z - bz * splits;
@@ -238,33 +261,37 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmOperand A, GemmOperand
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[2][4], rb[2][4];
-    if (k_begin < k_end) {
-        tn_load<T>(A, k_end, M, k_begin, m0, tid, mean_a, ra);
-        tn_load<T>(B, k_end, N, k_begin, n0, tid, mean_b, rb);
-    }
+    // threads 0..127 own operand A, 128..255 operand B (wave-uniform split)
+    const bool is_b = tid >= 128;
+    const int t = tid & 127;
+    const GemmOperand& op = is_b ? B : A;
+    const int cols = is_b ? N : M, col0 = is_b ? n0 : m0;
+    const float* mean = is_b ? mean_b : mean_a;
+    float* tile = is_b ? tB : tA;
+    float reg[2][4][4];
+    if (k_begin < k_end) tn_load<T, VEC>(op, k_end, cols, k_begin, col0, t, mean, reg);
     const int i = lane & 31, h = lane >> 5;
     for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
         __syncthreads();
-        tn_store_lds(tA, tid, ra);
-        tn_store_lds(tB, tid, rb);
+        tn_store_lds(tile, t, reg);
         __syncthreads();
-        if (k0 + TN_BK < k_end) {
-            tn_load<T>(A, k_end, M, k0 + TN_BK, m0, tid, mean_a, ra);
-            tn_load<T>(B, k_end, N, k0 + TN_BK, n0, tid, mean_b, rb);
-        }
+        if (k0 + TN_BK < k_end) tn_load<T, VEC>(op, k_end, cols, k0 + TN_BK, col0, t, mean, reg);
 #pragma unroll
-        for (int kk = 0; kk < TN_BK; kk += 2) {
-            float a[2], b[2];
+        for (int g = 0; g < TN_BK / 8; ++g) {
+            float4 a[2], b[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = tA[(kk + h) * TN_LD + wm * 64 + mi * 32 + i];
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const float4*)(tA + (((2 * g + h) * 128 + wm * 64 + mi * 32 + i) << 2));
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) b[ni] = tB[(kk + h) * TN_LD + wn * 64 + ni * 32 + i];
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const float4*)(tB + (((2 * g + h) * 128 + wn * 64 + ni * 32 + i) << 2));
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+                }
         }
     }
     store_tile(C, ldc, M, N, m0, n0, acc, wm, wn, lane, scale);
@@ -286,15 +313,21 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, long slab_s
 // Column means of a (rows x cols) strided token matrix: two-stage, deterministic.
 //   stage 1: grid = (ceil(cols/256), parts, batch) partial sums; stage 2 folds the parts.
 template <typename T>
-__global__ void colsum_partial_kernel(GemmOperand X, int rows, int cols, int parts, float* __restrict__ partial) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) colsum_partial_kernel(GemmOperand X, int rows, int cols, int parts,
+                                                             float* __restrict__ partial) {
+    // block = 64 columns x 4 row groups; grid = (ceil(cols/64), parts, batch)
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     const T* base = (const T*)X.ptr + (long)blockIdx.z * X.batch_stride;
     const int per = (rows + parts - 1) / parts;
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-    if (c >= cols) return;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += to_f32(base[row_off(X, r) + (long)c * X.sd]);
-    partial[((long)blockIdx.z * parts + blockIdx.y) * cols + c] = s;
+    if (c < cols)
+        for (int r = r0 + rg; r < r1; r += 4) s += to_f32(base[row_off(X, r) + (long)c * X.sd]);
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < cols)
+        partial[((long)blockIdx.z * parts + blockIdx.y) * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int cols, int parts, float inv_rows,
@@ -340,9 +373,9 @@ int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, in
 }
 
 int basd_gemm_tn_splits(int krows) {
-    int s = krows / 512;
+    int s = krows / 256;
     if (s < 1) s = 1;
-    if (s > 32) s = 32;
+    if (s > 64) s = 64;
     return s;
 }
 
@@ -363,12 +396,18 @@ int basd_gemm_tn(const void* a, const void* b, int dtype, long a_sb, long a_sn, 
     const long out_ld = splits == 1 ? ldc : N;
     const long z_stride = splits == 1 ? c_batch_stride : (long)M * N;
     const float k_scale = splits == 1 ? scale : 1.f;
-    if (dtype == BASD_DTYPE_F32)
-        gemm_tn_kernel<float><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
-    else if (dtype == BASD_DTYPE_BF16)
-        gemm_tn_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
-    else
+    const bool vec = dtype == BASD_DTYPE_F32 && a_sd == 1 && b_sd == 1 && aligned16(a) && aligned16(b) &&
+                     a_sb % 4 == 0 && a_sn % 4 == 0 && b_sb % 4 == 0 && b_sn % 4 == 0 && a_batch_stride % 4 == 0 &&
+                     b_batch_stride % 4 == 0;
+    if (dtype == BASD_DTYPE_F32) {
+        if (vec) gemm_tn_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+        else gemm_tn_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+    } else if (dtype == BASD_DTYPE_BF16) {
+        if (a_sd == 1 && b_sd == 1) gemm_tn_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+        else gemm_tn_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+    } else {
         return BASD_EINVAL;
+    }
     if (splits > 1) {
         const long count = (long)M * N;
         int blocks = (int)((count + 255) / 256);
@@ -380,9 +419,9 @@ int basd_gemm_tn(const void* a, const void* b, int dtype, long a_sb, long a_sn, 
 }
 
 int basd_colmean_parts(int rows) {
-    int p = rows / 256;
+    int p = rows / 128;
     if (p < 1) p = 1;
-    if (p > 64) p = 64;
+    if (p > 256) p = 256;
     return p;
 }
 
@@ -391,7 +430,7 @@ int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_p
                  int rows, int cols, int batch, int parts, float* partial, float* mean, hipStream_t stream) {
     BASD_CHECK_ARG(x && partial && mean && rows > 0 && cols > 0 && batch > 0 && parts >= 1);
     GemmOperand X{x, sb, sn, sd, rows_per_batch, batch_stride};
-    const dim3 grid((cols + 255) / 256, parts, batch);
+    const dim3 grid((cols + 63) / 64, parts, batch);
     if (dtype == BASD_DTYPE_F32) colsum_partial_kernel<float><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial);
     else if (dtype == BASD_DTYPE_BF16) colsum_partial_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial);
     else return BASD_EINVAL;

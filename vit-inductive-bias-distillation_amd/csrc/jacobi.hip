@@ -28,69 +28,141 @@
 
 namespace basd {
 
+// (4 eps)^2: squared relative size below which a column is numerically null
+constexpr float kNull2 = 2.2737368e-13f;
+
 struct Rot {
-    float c, s;    // fp32 cosine / sine of the plane rotation
-    float cl, sl;  // low parts: (c + cl)^2 + (s + sl)^2 = 1 to ~1e-14, so column norms do not drift
+    float c, s, t; // fp32 cosine / sine / tangent of the plane rotation
+    float h;       // (c^2 + s^2)(1 + h)^2 = 1 to ~1e-14: the rotation as applied shrinks both columns by (1 - h);
+                   // h is accumulated per column and folded back in once, at write-back
     bool apply;
 };
 
-// Rotation that makes columns p,q orthogonal given alpha=|p|^2, beta=|q|^2, gamma=p.q
+// Rotation that makes columns p,q orthogonal given alpha=|p|^2, beta=|q|^2, gamma=p.q.
+// The angle only has to be good enough for quadratic convergence, so it is built from the 1-ulp hardware
+// reciprocal / square-root instructions; what must be exact is c^2 + s^2 = 1, restored by the low parts.
 __device__ __forceinline__ Rot make_rotation(float alpha, float beta, float gamma, float tol) {
     Rot r{1.f, 0.f, 0.f, 0.f, false};
-    const float lim = tol * sqrtf(alpha) * sqrtf(beta);
-    if (!(fabsf(gamma) > lim) || gamma == 0.f) return r;
-    const float zeta = (beta - alpha) / (2.f * gamma);
-    float t;
-    if (fabsf(zeta) > 1e8f) {
-        t = 0.5f / zeta;
-    } else {
-        t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-    }
-    r.c = 1.f / sqrtf(1.f + t * t);
+    const float cosv = gamma * __builtin_amdgcn_rsqf(alpha) * __builtin_amdgcn_rsqf(beta);
+    if (!(fabsf(cosv) > tol)) return r;                      // also catches NaN and zero columns
+    const float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.f * gamma);
+    const float az = fabsf(zeta);
+    float t = az > 1e8f ? 0.5f * __builtin_amdgcn_rcpf(az)
+                        : __builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.f)));
+    t = copysignf(t, zeta);
+    r.t = t;
+    r.c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.f));
     r.s = r.c * t;
-    // fp32 c, s leave c^2 + s^2 = 1 + O(eps); over the ~n * sweeps rotations a column sees that is a random
-    // walk of its norm (measured 6e-6 relative at n = 96).  Fold the defect back in as low-order parts.
-    const double defect = 1.0 - (double)r.c * (double)r.c - (double)r.s * (double)r.s;
-    const float half = (float)(0.5 * defect);
-    r.cl = r.c * half;
-    r.sl = r.s * half;
+    // defect = 1 - c^2 - s^2 with error-free squares (c^2 in [0.5, 1]: the subtractions are exact);
+    // over the ~n * sweeps rotations a column sees, an O(eps) defect is a random walk of its norm
+    // (measured 6e-6 relative at n = 96 before this correction).
+    const float pc = r.c * r.c, ec = fmaf(r.c, r.c, -pc);
+    const float ps = r.s * r.s, es = fmaf(r.s, r.s, -ps);
+    r.h = 0.5f * ((((1.f - pc) - ps) - ec) - es);
     r.apply = true;
     return r;
 }
 
-// Orthogonalise LDS columns p and q (length rows_tot, dots over rows_dot) with a
-// group of `width` lanes; `gl` is the lane's index inside its group.
-__device__ __forceinline__ bool rotate_pair(float* __restrict__ cp, float* __restrict__ cq, int rows_dot,
-                                            int rows_tot, int gl, int width, float tol) {
-    float a = 0.f, b = 0.f, g = 0.f;
-    for (int r = gl; r < rows_dot; r += width) {
-        const float x = cp[r], y = cq[r];
-        a = fmaf(x, x, a);
-        b = fmaf(y, y, b);
-        g = fmaf(x, y, g);
+// ---- cross-lane sums without LDS: DPP inside a row of 16 lanes, lane-swaps across rows -------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+// Every lane of an (aligned) row of 16 ends with the row total; all 16 lanes must be active.
+__device__ __forceinline__ float row16_allsum(float x) {
+    x += dpp_get<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_get<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_get<0x141>(x);   // row_half_mirror
+    x += dpp_get<0x140>(x);   // row_mirror
+    return x;
+}
+__device__ __forceinline__ float wave64_allsum(float x) {
+    x = row16_allsum(x);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+template <int LPP>
+__device__ __forceinline__ float pair_allsum(float x) {
+    static_assert(LPP == 16 || LPP == 64, "a pair is owned by one DPP row or one wave");
+    return LPP == 16 ? row16_allsum(x) : wave64_allsum(x);
+}
+
+// Orthogonalise LDS columns p and q with one DPP row of 16 lanes (gl = lane index in the row).
+// LDS columns are zero-padded to 16 * EPL rows, dot rows first (padded to 16 * DOT), so lane gl owns rows
+// gl + 16 i, i < EPL, of which the first DOT enter the dot product: no per-element predicate at all, and
+// the elements stay in registers between the dot product and the update (one LDS read + one write each).
+//
+// Squared column norms are cached in LDS (n2p / n2q point at the two entries): they are recomputed from the
+// data once per sweep (LDS solver) or launch (block solver) and follow the rotations analytically in
+// between (alpha' = alpha - t gamma, beta' = beta + t gamma), so a pair-step needs ONE dot product.
+// devp / devq accumulate the normalisation defect h of every rotation applied to the column.
+//
+// null2: columns whose squared norm is below it are numerically null (sigma < 4 eps sigma_max, measured in
+// the previous sweep); they are pure round-off, never become "orthogonal relative to their own size", and
+// would keep the sweep loop alive for ever, so pairs involving them count as converged.
+template <int EPL, int DOT, int LPP>
+__device__ __forceinline__ bool rotate_pair(float* __restrict__ cp, float* __restrict__ cq, int gl, float tol,
+                                            float null2, float& norm2_max, float* __restrict__ n2p,
+                                            float* __restrict__ n2q, float* __restrict__ devp,
+                                            float* __restrict__ devq) {
+    float x[EPL], y[EPL];
+    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        x[i] = cp[gl + LPP * i];
+        y[i] = cq[gl + LPP * i];
+        if (i < DOT) {
+            if (i & 1) g1 = fmaf(x[i], y[i], g1);
+            else g0 = fmaf(x[i], y[i], g0);
+        }
     }
-    a = group_sum(a, width);
-    b = group_sum(b, width);
-    g = group_sum(g, width);
-    const Rot rot = make_rotation(a, b, g, tol);
+    const float g = pair_allsum<LPP>(g0 + g1);
+    const float a = *n2p, b = *n2q;
+    norm2_max = fmaxf(norm2_max, fmaxf(a, b));
+    if (fminf(a, b) <= null2) return false;
+    const Rot rot = make_rotation(a, b, g, tol);   // identical in every lane of the row
     if (!rot.apply) return false;
-    for (int r = gl; r < rows_tot; r += width) {
-        const float x = cp[r], y = cq[r];
-        cp[r] = fmaf(rot.c, x, fmaf(-rot.s, y, fmaf(rot.cl, x, -rot.sl * y)));
-        cq[r] = fmaf(rot.s, x, fmaf(rot.c, y, fmaf(rot.sl, x, rot.cl * y)));
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        cp[gl + LPP * i] = fmaf(rot.c, x[i], -rot.s * y[i]);
+        cq[gl + LPP * i] = fmaf(rot.s, x[i], rot.c * y[i]);
+    }
+    if (gl == 0) {
+        *n2p = fmaxf(a - rot.t * g, 0.f);
+        *n2q = b + rot.t * g;
+        *devp += rot.h;
+        *devq += rot.h;
     }
     return true;
 }
 
+// exact squared norm (over the dot rows) of one padded LDS column, by one DPP row
+template <int DOT, int LPP>
+__device__ __forceinline__ float column_norm2(const float* __restrict__ col, int gl) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < DOT; ++i) a = fmaf(col[gl + LPP * i], col[gl + LPP * i], a);
+    return pair_allsum<LPP>(a);
+}
+
+// LDS row of global row r: dot rows first, the riding rows start at the next multiple of 16
+template <int EPL, int DOT, int LPP>
+__device__ __forceinline__ int lds_row(int r, int rows_dot) {
+    return (DOT == EPL || r < rows_dot) ? r : LPP * DOT + (r - rows_dot);
+}
+
 // ---------------------------------------------------------------------------
-// LDS-resident solver.  grid = batch, block = multiple of 64.
+// LDS-resident solver.  grid = batch, block = multiple of 64; a pair = one DPP row of 16 lanes.
+// DOT == EPL: rows_dot == rows_tot <= 16 EPL.   DOT < EPL: rows_dot <= 16 DOT, rows_tot - rows_dot <= 16 (EPL - DOT).
 // ---------------------------------------------------------------------------
-template <int LPP>
+template <int EPL, int DOT>
 __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W, long batch_stride, int rows_dot,
                                                            int rows_tot, int n_fixed, const int* __restrict__ n_arr,
-                                                           int ld, int max_sweeps, float tol,
-                                                           float* __restrict__ colnorm, int colnorm_stride,
-                                                           int* __restrict__ sweeps_out) {
+                                                           int max_sweeps, float tol, float* __restrict__ colnorm,
+                                                           int colnorm_stride, int* __restrict__ sweeps_out) {
+    constexpr int LD = 16 * EPL + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m = blockIdx.x;
     int n = n_arr ? n_arr[m] : n_fixed;
@@ -105,104 +177,190 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
         if (sweeps_out && tid == 0) sweeps_out[m] = 0;
         return;
     }
-    // global (ld = rows_tot) -> LDS (ld = `ld`, odd)
+    const int n_even = (n + 1) & ~1;
+    for (int idx = tid; idx < n_even * LD; idx += nthr) lds[idx] = 0.f;
+    __syncthreads();
+    // global (leading dim rows_tot) -> padded LDS columns
     for (int idx = tid; idx < n * rt; idx += nthr) {
         const int c = idx / rt, r = idx - c * rt;
-        lds[c * ld + r] = Wm[(long)c * rows_tot + r];
+        lds[c * LD + lds_row<EPL, DOT, 16>(r, rd)] = Wm[(long)c * rows_tot + r];
     }
     __syncthreads();
 
-    const int n_even = (n + 1) & ~1;
-    const int groups = nthr / LPP, grp = tid / LPP, gl = tid % LPP;
+    const int groups = nthr / 16, grp = tid / 16, gl = tid % 16;
+    float* n2 = lds + n_even * LD;      // cached squared column norms
+    float* dev = n2 + n_even;           // accumulated normalisation defects
+    __shared__ int s_norm2_bits;
+    if (tid == 0) s_norm2_bits = 0;
+    for (int c = tid; c < n_even; c += nthr) dev[c] = 0.f;
+    float null2 = 0.f;
     int sweep = 0;
     for (; sweep < max_sweeps && n > 1; ++sweep) {
         int rotated = 0;
+        float norm2_max = 0.f;
+        for (int c = grp; c < n_even; c += groups) {          // refresh the cached norms from the data
+            const float v = column_norm2<DOT, 16>(lds + c * LD, gl);
+            if (gl == 0) n2[c] = v;
+        }
+        __syncthreads();
         for (int r = 0; r < n_even - 1; ++r) {
             for (int t = grp; t < n_even / 2; t += groups) {
                 int p, q;
                 rr_pair(n_even, r, t, p, q);
                 if (p >= n || q >= n) continue;  // padding column of an odd-order matrix
                 if (p > q) { const int tmp = p; p = q; q = tmp; }
-                rotated |= rotate_pair(lds + p * ld, lds + q * ld, rd, rt, gl, LPP, tol) ? 1 : 0;
+                rotated |= rotate_pair<EPL, DOT, 16>(lds + p * LD, lds + q * LD, gl, tol, null2, norm2_max, n2 + p, n2 + q,
+                                                 dev + p, dev + q) ? 1 : 0;
             }
             __syncthreads();
         }
+        if (gl == 0 && norm2_max > 0.f) atomicMax(&s_norm2_bits, __float_as_int(norm2_max));
         if (!__syncthreads_or(rotated)) {
             ++sweep;
             break;
         }
+        null2 = kNull2 * __int_as_float(s_norm2_bits);   // every column norm of this sweep has been folded in
     }
     if (sweeps_out && tid == 0) sweeps_out[m] = sweep;
 
-    // column norms over the dot rows + write back
+    // column norms over the dot rows + write back, both with the accumulated defect folded in
     for (int c = grp; c < n; c += groups) {
-        float a = 0.f;
-        for (int r = gl; r < rd; r += LPP) a = fmaf(lds[c * ld + r], lds[c * ld + r], a);
-        a = group_sum(a, LPP);
-        if (gl == 0) colnorm[(long)m * colnorm_stride + c] = sqrtf(a);
+        const float a = column_norm2<DOT, 16>(lds + c * LD, gl);
+        if (gl == 0) {
+            const float nv = sqrtf(a);
+            colnorm[(long)m * colnorm_stride + c] = fmaf(nv, dev[c], nv);
+        }
     }
     for (int idx = tid; idx < n * rt; idx += nthr) {
         const int c = idx / rt, r = idx - c * rt;
-        Wm[(long)c * rows_tot + r] = lds[c * ld + r];
+        const float v = lds[c * LD + lds_row<EPL, DOT, 16>(r, rd)];
+        Wm[(long)c * rows_tot + r] = fmaf(v, dev[c], v);
     }
 }
 
 // ---------------------------------------------------------------------------
 // Block solver: one launch = one round-robin round over column blocks.
-// grid = (nblk/2, batch), block = 64 * BW threads (one wave per column pair).
-// flags[m * max_sweeps + s] != 0  <=>  some rotation was applied in sweep s.
+// grid = (nblk/2, batch), block = 64 * BW threads: one WAVE per column pair (16 waves keep the four SIMDs'
+// issue slots busy; a lone wave per SIMD issues one VALU instruction every 4 cycles instead of every 2).
+// Columns are padded to 64 * EPL rows.  flags[m * max_sweeps + s] != 0 <=> a rotation was applied in sweep s.
 // ---------------------------------------------------------------------------
-template <int BW>
+template <int BW, int EPL, int DOT>
 __global__ void __launch_bounds__(64 * BW) jacobi_block_round_kernel(float* __restrict__ W, long batch_stride,
                                                                      int rows_dot, int rows_tot, int n, int nblk,
-                                                                     int round, int sweep, int max_sweeps, int ld,
-                                                                     float tol, int* __restrict__ flags) {
+                                                                     int round, int sweep, int max_sweeps,
+                                                                     float tol, int* __restrict__ flags,
+                                                                     int* __restrict__ norm2_bits) {
+    constexpr int LPP = 64;
+    constexpr int LD = LPP * EPL + 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m = blockIdx.y;
     if (sweep > 0 && flags[m * max_sweeps + sweep - 1] == 0) return;  // converged in an earlier sweep
+    const float null2 = sweep > 0 ? kNull2 * __int_as_float(norm2_bits[m * max_sweeps + sweep - 1]) : 0.f;
+    float norm2_max = 0.f;
     int bi, bj;
     rr_pair(nblk, round, blockIdx.x, bi, bj);
     if (bi > bj) { const int t = bi; bi = bj; bj = t; }
     float* Wm = W + (long)m * batch_stride;
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
+    const int grp = tid / LPP, gl = tid % LPP;
 
-    // stage the 2*BW columns (zero-fill columns >= n)
-    for (int idx = tid; idx < 2 * BW * rows_tot; idx += nthr) {
-        const int lc = idx / rows_tot, r = idx - lc * rows_tot;
-        const int gc = (lc < BW ? bi * BW + lc : bj * BW + (lc - BW));
-        lds[lc * ld + r] = gc < n ? Wm[(long)gc * rows_tot + r] : 0.f;
+    // stage the 2*BW columns (zero-padded rows, zero columns >= n).  The panel is tiny next to the launch's
+    // latency budget, so what matters is loads in flight: every thread issues several independent 16-byte
+    // loads before the first LDS write.
+    constexpr int NT = LPP * BW;
+    const bool padded = rows_tot != LPP * EPL || (bi + 1) * BW > n || (bj + 1) * BW > n;
+    if (padded) {
+        for (int idx = tid; idx < 2 * BW * LD; idx += NT) lds[idx] = 0.f;
+        __syncthreads();
+    }
+    const bool vec4 = (rows_tot & 3) == 0 && (batch_stride & 3) == 0 && (((uintptr_t)W) & 15) == 0;
+    if (vec4) {
+        const int q4 = rows_tot >> 2, total4 = 2 * BW * q4;
+#pragma unroll 4
+        for (int idx = tid; idx < total4; idx += NT) {
+            const int lc = idx / q4, r = (idx - lc * q4) << 2;
+            const int gc = (lc < BW ? bi * BW + lc : bj * BW + (lc - BW));
+            if (gc < n) {
+                const float4 v = *(const float4*)(Wm + (long)gc * rows_tot + r);
+                float* col = lds + lc * LD;
+                col[lds_row<EPL, DOT, LPP>(r, rows_dot)] = v.x;
+                col[lds_row<EPL, DOT, LPP>(r + 1, rows_dot)] = v.y;
+                col[lds_row<EPL, DOT, LPP>(r + 2, rows_dot)] = v.z;
+                col[lds_row<EPL, DOT, LPP>(r + 3, rows_dot)] = v.w;
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int idx = tid; idx < 2 * BW * rows_tot; idx += NT) {
+            const int lc = idx / rows_tot, r = idx - lc * rows_tot;
+            const int gc = (lc < BW ? bi * BW + lc : bj * BW + (lc - BW));
+            if (gc < n) lds[lc * LD + lds_row<EPL, DOT, LPP>(r, rows_dot)] = Wm[(long)gc * rows_tot + r];
+        }
+    }
+    float* n2 = lds + 2 * BW * LD;      // cached squared column norms
+    float* dev = n2 + 2 * BW;           // accumulated normalisation defects
+    __syncthreads();
+    for (int c = grp; c < 2 * BW; c += BW) {
+        const float v = column_norm2<DOT, LPP>(lds + c * LD, gl);
+        if (gl == 0) { n2[c] = v; dev[c] = 0.f; }
     }
     __syncthreads();
 
     int rotated = 0;
     if (round == 0) {
-        // pairs inside block I (waves 0..BW/2-1) and inside block J (waves BW/2..BW-1)
-        const int half = wave / (BW / 2), t = wave % (BW / 2), base = half * BW;
+        // pairs inside block I (rows 0..BW/2-1) and inside block J (rows BW/2..BW-1)
+        const int half = grp / (BW / 2), t = grp % (BW / 2), base = half * BW;
         for (int r = 0; r < BW - 1; ++r) {
             int p, q;
             rr_pair(BW, r, t, p, q);
             if (p > q) { const int tmp = p; p = q; q = tmp; }
             const int gp = (half ? bj : bi) * BW + p, gq = (half ? bj : bi) * BW + q;
             if (gp < n && gq < n)
-                rotated |= rotate_pair(lds + (base + p) * ld, lds + (base + q) * ld, rows_dot, rows_tot, lane, 64, tol);
+                rotated |= rotate_pair<EPL, DOT, LPP>(lds + (base + p) * LD, lds + (base + q) * LD, gl, tol, null2, norm2_max,
+                                                 n2 + base + p, n2 + base + q, dev + base + p, dev + base + q);
             __syncthreads();
         }
     }
-    // cross pairs: column `wave` of I with column (wave + r) % BW of J
+    // cross pairs: column `grp` of I with column (grp + r) % BW of J
     for (int r = 0; r < BW; ++r) {
-        const int p = wave, q = (wave + r) % BW;
+        const int p = grp, q = (grp + r) % BW;
         const int gp = bi * BW + p, gq = bj * BW + q;
         if (gp < n && gq < n)
-            rotated |= rotate_pair(lds + p * ld, lds + (BW + q) * ld, rows_dot, rows_tot, lane, 64, tol);
+            rotated |= rotate_pair<EPL, DOT, LPP>(lds + p * LD, lds + (BW + q) * LD, gl, tol, null2, norm2_max, n2 + p,
+                                             n2 + BW + q, dev + p, dev + BW + q);
         __syncthreads();
     }
+    if (gl == 0 && norm2_max > 0.f) atomicMax(&norm2_bits[m * max_sweeps + sweep], __float_as_int(norm2_max));
     if (__syncthreads_or(rotated) && tid == 0) atomicOr(&flags[m * max_sweeps + sweep], 1);
 
-    for (int idx = tid; idx < 2 * BW * rows_tot; idx += nthr) {
-        const int lc = idx / rows_tot, r = idx - lc * rows_tot;
-        const int gc = (lc < BW ? bi * BW + lc : bj * BW + (lc - BW));
-        if (gc < n) Wm[(long)gc * rows_tot + r] = lds[lc * ld + r];
+    if (vec4) {
+        const int q4 = rows_tot >> 2, total4 = 2 * BW * q4;
+#pragma unroll 4
+        for (int idx = tid; idx < total4; idx += NT) {
+            const int lc = idx / q4, r = (idx - lc * q4) << 2;
+            const int gc = (lc < BW ? bi * BW + lc : bj * BW + (lc - BW));
+            if (gc < n) {
+                const float* col = lds + lc * LD;
+                const float dv = dev[lc];
+                float4 v;
+                v.x = col[lds_row<EPL, DOT, LPP>(r, rows_dot)];
+                v.y = col[lds_row<EPL, DOT, LPP>(r + 1, rows_dot)];
+                v.z = col[lds_row<EPL, DOT, LPP>(r + 2, rows_dot)];
+                v.w = col[lds_row<EPL, DOT, LPP>(r + 3, rows_dot)];
+                v.x = fmaf(v.x, dv, v.x); v.y = fmaf(v.y, dv, v.y); v.z = fmaf(v.z, dv, v.z); v.w = fmaf(v.w, dv, v.w);
+                *(float4*)(Wm + (long)gc * rows_tot + r) = v;
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int idx = tid; idx < 2 * BW * rows_tot; idx += NT) {
+            const int lc = idx / rows_tot, r = idx - lc * rows_tot;
+            const int gc = (lc < BW ? bi * BW + lc : bj * BW + (lc - BW));
+            if (gc < n) {
+                const float v = lds[lc * LD + lds_row<EPL, DOT, LPP>(r, rows_dot)];
+                Wm[(long)gc * rows_tot + r] = fmaf(v, dev[lc], v);
+            }
+        }
     }
 }
 
@@ -272,14 +430,13 @@ __global__ void __launch_bounds__(256) sort_extract_kernel(const float* __restri
 
 using namespace basd;
 
-static inline int lds_ld(int rows) { return rows | 1; }
 
 extern "C" {
 
 // Largest LDS the resident solver may use (bytes); leaves room for the runtime.
 #define BASD_JACOBI_LDS_LIMIT (156 * 1024)
 
-int basd_jacobi_workspace_ints(int batch, int max_sweeps) { return batch * max_sweeps; }
+int basd_jacobi_workspace_ints(int batch, int max_sweeps) { return 2 * batch * max_sweeps; }
 
 // One-sided Jacobi on `batch` column-major matrices (rows_tot x n, leading dim rows_tot).
 //   n_arr (device, nullable): per-matrix order for square problems (rows = n_arr[m]); the
@@ -293,43 +450,95 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
     BASD_CHECK_ARG(W && colnorm && rows_dot > 0 && rows_tot >= rows_dot && n > 0 && batch > 0 && max_sweeps > 0);
     const float tol = 1.2e-7f * sqrtf((float)rows_dot);
     const int n_even = (n + 1) & ~1;
-    const int ld = lds_ld(rows_tot);
-    const size_t lds_bytes = (size_t)n_even * ld * sizeof(float);
-    if (lds_bytes <= BASD_JACOBI_LDS_LIMIT) {
-        // lanes per pair: enough lanes to cover the column, few enough that a round fits the block
-        const int pairs = n_even / 2;
-        int lpp = rows_tot >= 256 ? 64 : rows_tot >= 96 ? 32 : rows_tot >= 40 ? 16 : 8;
-        int threads = pairs * lpp;
-        threads = ((threads + 63) / 64) * 64;
+    // per-lane element counts of the zero-padded LDS columns (16 lanes per column pair)
+    const bool stacked = rows_tot > rows_dot;
+    const int dot16 = (rows_dot + 15) / 16, ride16 = (rows_tot - rows_dot + 15) / 16;
+    const int half = dot16 > ride16 ? dot16 : ride16;          // stacked layouts: EPL = 2 * DOT
+    const int epl = stacked ? 2 * half : dot16;
+    BASD_CHECK_ARG(!(stacked && n_arr));
+
+    // ---- LDS-resident: the whole (padded) matrix in one CU ----
+    static const int lds_epl[] = {2, 4, 6, 8, 12, 16, 20};
+    int e_lds = 0;
+    for (int e : lds_epl)
+        if (e >= epl && (!stacked || e % 2 == 0)) { e_lds = e; break; }
+    if (e_lds && (size_t)n_even * (16 * e_lds + 3) * sizeof(float) <= BASD_JACOBI_LDS_LIMIT) {
+        const size_t lds_bytes = (size_t)n_even * (16 * e_lds + 3) * sizeof(float);
+        // every pair of a round-robin round in flight at once when it fits the block
+        int threads = (((n_even / 2) * 16 + 63) / 64) * 64;
         if (threads > 1024) threads = 1024;
-        if (threads < 64) threads = 64;
-#define LAUNCH_LDS(L)                                                                                         \
-    (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
-                        BASD_JACOBI_LDS_LIMIT);                                                               \
-    jacobi_lds_kernel<L><<<batch, threads, lds_bytes, stream>>>(W, batch_stride, rows_dot, rows_tot, n, n_arr, \
-                                                                 ld, max_sweeps, tol, colnorm, colnorm_stride, \
-                                                                 sweeps_out)
-        if (lpp == 64) { LAUNCH_LDS(64); }
-        else if (lpp == 32) { LAUNCH_LDS(32); }
-        else if (lpp == 16) { LAUNCH_LDS(16); }
-        else { LAUNCH_LDS(8); }
+#define LAUNCH_LDS(E, D)                                                                                          \
+    do {                                                                                                          \
+        if (lds_bytes > 48 * 1024)                                                                                \
+            (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<E, D>,                                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BASD_JACOBI_LDS_LIMIT);         \
+        jacobi_lds_kernel<E, D><<<batch, threads, lds_bytes, stream>>>(W, batch_stride, rows_dot, rows_tot, n,    \
+                                                                        n_arr, max_sweeps, tol, colnorm,           \
+                                                                        colnorm_stride, sweeps_out);               \
+    } while (0)
+#define LAUNCH_LDS_E(E)                 \
+    do {                                \
+        if (stacked) LAUNCH_LDS(E, E / 2); \
+        else LAUNCH_LDS(E, E);          \
+    } while (0)
+        switch (e_lds) {
+            case 2: LAUNCH_LDS_E(2); break;
+            case 4: LAUNCH_LDS_E(4); break;
+            case 6: LAUNCH_LDS_E(6); break;
+            case 8: LAUNCH_LDS_E(8); break;
+            case 12: LAUNCH_LDS_E(12); break;
+            case 16: LAUNCH_LDS_E(16); break;
+            default: LAUNCH_LDS_E(20); break;
+        }
+#undef LAUNCH_LDS_E
 #undef LAUNCH_LDS
         BASD_RETURN_LAST();
     }
+
+    // ---- block path: one launch per round-robin round over blocks of BW columns ----
     BASD_CHECK_ARG(n_arr == nullptr && flags != nullptr);
     constexpr int BW = 16;
     int nblk = (n + BW - 1) / BW;
     nblk = (nblk + 1) & ~1;
-    const size_t panel_bytes = (size_t)2 * BW * ld * sizeof(float);
+    // per-lane element counts with one wave (64 lanes) per column pair
+    const int dot64 = (rows_dot + 63) / 64, ride64 = (rows_tot - rows_dot + 63) / 64;
+    const int half64 = dot64 > ride64 ? dot64 : ride64;
+    const int epl64 = stacked ? 2 * half64 : dot64;
+    static const int blk_epl[] = {2, 4, 6, 8, 12, 16};
+    int e_blk = 0;
+    for (int e : blk_epl)
+        if (e >= epl64) { e_blk = e; break; }
+    if (!e_blk) return BASD_EUNSUPPORTED;                        // more than 1024 (padded) rows
+    const size_t panel_bytes = (size_t)2 * BW * (64 * e_blk + 3) * sizeof(float);
     if (panel_bytes > BASD_JACOBI_LDS_LIMIT) return BASD_EUNSUPPORTED;
-    hipError_t e = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)batch * max_sweeps, stream);
-    if (e != hipSuccess) return (int)e;
-    (void)hipFuncSetAttribute((const void*)jacobi_block_round_kernel<BW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        BASD_JACOBI_LDS_LIMIT);
-    for (int s = 0; s < max_sweeps; ++s)
-        for (int r = 0; r < nblk - 1; ++r)
-            jacobi_block_round_kernel<BW><<<dim3(nblk / 2, batch), 64 * BW, panel_bytes, stream>>>(
-                W, batch_stride, rows_dot, rows_tot, n, nblk, r, s, max_sweeps, ld, tol, flags);
+    hipError_t err = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)2 * batch * max_sweeps, stream);
+    if (err != hipSuccess) return (int)err;
+#define LAUNCH_BLOCK(E, D)                                                                                       \
+    do {                                                                                                         \
+        if (panel_bytes > 48 * 1024)                                                                             \
+            (void)hipFuncSetAttribute((const void*)jacobi_block_round_kernel<BW, E, D>,                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BASD_JACOBI_LDS_LIMIT);        \
+        for (int s = 0; s < max_sweeps; ++s)                                                                     \
+            for (int r = 0; r < nblk - 1; ++r)                                                                   \
+                jacobi_block_round_kernel<BW, E, D><<<dim3(nblk / 2, batch), 64 * BW, panel_bytes, stream>>>(    \
+                    W, batch_stride, rows_dot, rows_tot, n, nblk, r, s, max_sweeps, tol, flags,                  \
+                    flags + (size_t)batch * max_sweeps);                                                         \
+    } while (0)
+#define LAUNCH_BLOCK_E(E)                    \
+    do {                                     \
+        if (stacked) LAUNCH_BLOCK(E, E / 2); \
+        else LAUNCH_BLOCK(E, E);             \
+    } while (0)
+    switch (e_blk) {
+        case 2: LAUNCH_BLOCK_E(2); break;
+        case 4: LAUNCH_BLOCK_E(4); break;
+        case 6: LAUNCH_BLOCK_E(6); break;
+        case 8: LAUNCH_BLOCK_E(8); break;
+        case 12: LAUNCH_BLOCK_E(12); break;
+        default: LAUNCH_BLOCK_E(16); break;
+    }
+#undef LAUNCH_BLOCK_E
+#undef LAUNCH_BLOCK
     colnorm_kernel<<<dim3((n + 3) / 4, batch), 256, 0, stream>>>(W, batch_stride, rows_dot, rows_tot, n, colnorm,
                                                                  colnorm_stride);
     BASD_RETURN_LAST();

@@ -109,8 +109,9 @@ __global__ void __launch_bounds__(256) token_weights_kernel(const void* const* _
 
 // ---------------------------------------------------------------------------
 // Student side: weighted mean, trace, and the down-projection A' = I^T diag(w) (X - 1 mu^T).
-// grid = B, block = 256.   X: (B, N_s, D) strided (feature stride 1).
+// grid = (ceil(D/64), B), block = 256 = 64 features x 4 row groups.   X: (B, N_s, D), feature stride 1.
 //   range0/range1: for teacher token j, student rows [range0[j], range1[j]) touch it (null = identity grid)
+//   tr_part: (B, nslab) partial traces, one per 64-feature slab (summed in fixed order by the finalize kernel)
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) student_project_kernel(const T* __restrict__ X, long sb, long sn, int n_s,
@@ -120,53 +121,55 @@ __global__ void __launch_bounds__(256) student_project_kernel(const T* __restric
                                                               const float* __restrict__ lam,
                                                               const int* __restrict__ range0,
                                                               const int* __restrict__ range1,
-                                                              float* __restrict__ mu_out, float* __restrict__ tr_out,
+                                                              float* __restrict__ mu_out, float* __restrict__ tr_part,
                                                               float* __restrict__ Ap) {
     extern __shared__ float sm[];
-    float* mu = sm;        // D
-    float* w = sm + D;     // n_s
-    __shared__ float red[32];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const T* Xb = X + (long)b * sb;
+    float* w = sm;                 // n_s
+    __shared__ float red[4][64];
+    __shared__ float mu[64];
+    __shared__ float scratch[32];
+    const int b = blockIdx.y, d0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int cl = tid & 63, rg = tid >> 6, d = d0 + cl;
+    const bool live = d < D;
+    const T* Xb = X + (long)b * sb + d;
     for (int n = tid; n < n_s; n += 256) w[n] = omega[(long)b * n_s + n];
     __syncthreads();
-    for (int d = tid; d < D; d += 256) {
-        float acc = 0.f;
-        for (int n = 0; n < n_s; ++n) acc = fmaf(w[n], to_f32(Xb[(long)n * sn + d]), acc);
-        mu[d] = acc;
-        mu_out[(long)b * D + d] = acc;
+    float acc = 0.f;
+    if (live)
+        for (int n = rg; n < n_s; n += 4) acc = fmaf(w[n], to_f32(Xb[(long)n * sn]), acc);
+    red[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        const float m = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        mu[cl] = m;
+        if (live) mu_out[(long)b * D + d] = m;
     }
     __syncthreads();
-    // trace: sum_n w_n |x_n - mu|^2
+    const float m = mu[cl];
+    // trace: sum_n w_n (x_n - mu)^2 over this slab
     float part = 0.f;
-    for (int n = 0; n < n_s; ++n) {
-        float rowacc = 0.f;
-        for (int d = tid; d < D; d += 256) {
-            const float c = to_f32(Xb[(long)n * sn + d]) - mu[d];
-            rowacc = fmaf(c, c, rowacc);
+    if (live)
+        for (int n = rg; n < n_s; n += 4) {
+            const float c = to_f32(Xb[(long)n * sn]) - m;
+            part = fmaf(w[n] * c, c, part);
         }
-        part = fmaf(w[n], rowacc, part);
-    }
-    const float tr = block_sum(part, red);
-    if (tid == 0) tr_out[b] = tr;
-    // A'[j, :] = sum_n I[n, j] w_n (x_n - mu)
-    float* Ab = Ap + (long)b * n_t * D;
-    for (int j = 0; j < n_t; ++j) {
+    const float tr = block_sum(part, scratch);
+    if (tid == 0) tr_part[(long)b * gridDim.x + blockIdx.x] = tr;
+    // A'[j, d] = sum_n I[n, j] w_n (x_n - mu)
+    if (!live) return;
+    float* Ab = Ap + (long)b * n_t * D + d;
+    for (int j = rg; j < n_t; j += 4) {
         const int n0 = range0 ? range0[j] : j, n1 = range1 ? range1[j] : j + 1;
-        for (int d = tid; d < D; d += 256) {
-            float acc = 0.f;
-            for (int n = n0; n < n1; ++n) {
-                float coef;
-                if (tap0) {
-                    const float l1 = lam[n];
-                    coef = (tap0[n] == j ? 1.f - l1 : 0.f) + (tap1[n] == j ? l1 : 0.f);
-                } else {
-                    coef = 1.f;
-                }
-                acc = fmaf(coef * w[n], to_f32(Xb[(long)n * sn + d]) - mu[d], acc);
+        float a = 0.f;
+        for (int n = n0; n < n1; ++n) {
+            float coef = 1.f;
+            if (tap0) {
+                const float l1 = lam[n];
+                coef = (tap0[n] == j ? 1.f - l1 : 0.f) + (tap1[n] == j ? l1 : 0.f);
             }
-            Ab[(long)j * D + d] = acc;
+            a = fmaf(coef * w[n], to_f32(Xb[(long)n * sn]) - m, a);
         }
+        Ab[(long)j * D] = a;
     }
 }
 
@@ -406,8 +409,8 @@ __global__ void __launch_bounds__(256) procrustes_finalize_kernel(
     const float* __restrict__ W, long w_batch_stride, const float* __restrict__ sigma, int n, int n_s,
     const double* __restrict__ Gb, long g_batch_stride, const float* __restrict__ omega,
     const int* __restrict__ tap0, const int* __restrict__ tap1, const float* __restrict__ lam,
-    const float* __restrict__ tr_s, float* __restrict__ tr_t_out, float* __restrict__ nuc_out,
-    float* __restrict__ loss_out, float* __restrict__ Kp) {
+    const float* __restrict__ tr_s, int tr_slabs, float* __restrict__ tr_s_out, float* __restrict__ tr_t_out,
+    float* __restrict__ nuc_out, float* __restrict__ loss_out, float* __restrict__ Kp) {
     extern __shared__ float sm[];
     float* isig = sm;                      // n : 1/sigma_j or 0 when truncated
     __shared__ float red[32];
@@ -442,9 +445,12 @@ __global__ void __launch_bounds__(256) procrustes_finalize_kernel(
     }
     const double trt = block_sum(part, redd);
     if (tid == 0) {
+        float trs = 0.f;
+        for (int k = 0; k < tr_slabs; ++k) trs += tr_s[(long)b * tr_slabs + k];
+        tr_s_out[b] = trs;
         tr_t_out[b] = (float)trt;
         nuc_out[b] = nuc;
-        loss_out[b] = tr_s[b] + (float)trt - 2.f * nuc;
+        loss_out[b] = trs + (float)trt - 2.f * nuc;
     }
     __syncthreads();
     if (Kp) {
@@ -567,16 +573,18 @@ int basd_token_weights(const void* const* attn_ptrs, int dtype, const float* mix
 }
 
 // relational.py:36-45 (student half) + the transpose of combined.py:9-14.
+// tr_s: (B, ceil(D/64)) per-slab partial traces (summed by basd_procrustes_finalize).
 int basd_student_project(const void* x, int dtype, long sb, long sn, int B, int n_s, int n_t, int D,
                          const float* omega, const int* tap0, const int* tap1, const float* lam, const int* range0,
                          const int* range1, float* mu, float* tr_s, float* a_prime, hipStream_t stream) {
     BASD_CHECK_ARG(x && omega && mu && tr_s && a_prime && B > 0 && n_s > 0 && n_t > 0 && D > 0);
     BASD_CHECK_ARG((n_t == n_s) == (tap0 == nullptr));
-    const size_t lds = sizeof(float) * (size_t)(D + n_s);
+    const size_t lds = sizeof(float) * (size_t)n_s;
+    const dim3 grid((D + 63) / 64, B);
     if (dtype == BASD_DTYPE_F32)
-        student_project_kernel<float><<<B, 256, lds, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+        student_project_kernel<float><<<grid, 256, lds, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
     else if (dtype == BASD_DTYPE_BF16)
-        student_project_kernel<__hip_bfloat16><<<B, 256, lds, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+        student_project_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
     else
         return BASD_EINVAL;
     BASD_RETURN_LAST();
@@ -639,13 +647,13 @@ int basd_stack_product(const double* la, const double* lb, long l_batch_stride, 
 // relational.py:45-50 per sample: tr_t, nuclear norm, loss_b = tr_s + tr_t - 2 nuc; K' for backward (nullable).
 int basd_procrustes_finalize(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
                              const double* gb, long g_batch_stride, const float* omega, const int* tap0,
-                             const int* tap1, const float* lam, const float* tr_s, float* tr_t, float* nuc,
-                             float* loss, float* k_prime, hipStream_t stream) {
-    BASD_CHECK_ARG(w && sigma && gb && omega && tr_s && tr_t && nuc && loss && n > 0 && batch > 0);
+                             const int* tap1, const float* lam, const float* tr_s_part, int tr_slabs, float* tr_s,
+                             float* tr_t, float* nuc, float* loss, float* k_prime, hipStream_t stream) {
+    BASD_CHECK_ARG(w && sigma && gb && omega && tr_s_part && tr_s && tr_t && nuc && loss && n > 0 && batch > 0 && tr_slabs > 0);
     const size_t lds = sizeof(float) * ((size_t)n + (k_prime ? (size_t)n * n : 0));
     if (lds > 156 * 1024) return BASD_EUNSUPPORTED;
     (void)hipFuncSetAttribute((const void*)procrustes_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    procrustes_finalize_kernel<<<batch, 256, lds, stream>>>(w, w_batch_stride, sigma, n, n_s, gb, g_batch_stride, omega, tap0, tap1, lam, tr_s, tr_t, nuc, loss, k_prime);
+    procrustes_finalize_kernel<<<batch, 256, lds, stream>>>(w, w_batch_stride, sigma, n, n_s, gb, g_batch_stride, omega, tap0, tap1, lam, tr_s_part, tr_slabs, tr_s, tr_t, nuc, loss, k_prime);
     BASD_RETURN_LAST();
 }
 
