@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "vit-inductive-bias-distillation_amd"))
 import torch
 import torch.distributed as dist
 
-from basd_amd import _lib, synth
+from basd_amd import _lib, ddp, ops, synth
 from basd_amd.losses import BASDLoss
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -55,31 +55,33 @@ def build(shape: synth.LossShape, cfg: str, device):
                     teacher_has_cls_token=shape.has_cls).to(device)
 
 
-def one_step(mod, inp, leaves, logits, grad_buf, world):
+def one_step(mod, inp, leaves, logits, bucket):
     for v in leaves.values():
         v.grad = None
     logits.grad = None
     mod.layer_selector.log_temperatures.grad = None
     loss = mod(logits, inp.targets, leaves, inp.teacher, inp.attn)
     loss.backward()
-    # stand-in head: per-feature bias gradients of every extraction layer + the selector temperatures
+    # stand-in student head: per-feature bias gradients of every extraction layer fill the front of the
+    # student part of the bucket (the rest keeps its DeiT-S size so that the all-reduce volume is real)
     off = 0
     for l in mod.token_layers:
         g = leaves[l].grad
         d = g.shape[-1]
-        grad_buf[off:off + d] = g.sum(dim=(0, 1))
+        bucket.student_view[off:off + d] = g.sum(dim=(0, 1))
         off += d
-    grad_buf[-4:] = mod.layer_selector.log_temperatures.grad
-    if world > 1:
-        dist.all_reduce(grad_buf, op=dist.ReduceOp.SUM)
-        grad_buf.div_(world)
+    bucket.pack_loss_grads()            # + the 4 selector temperatures the reference forgets to reduce
+    bucket.all_reduce_mean()            # RCCL over xGMI; no-op at world size 1
     return loss
 
 
 def cpu_baseline(cfg: str, shape: synth.LossShape, sample_batch: int) -> dict:
     """The CPU oracle (restatement of the reference, pinned by tests/golden) on a bounded sample."""
     from oracle import basd_oracle as O
-    cores = torch.get_num_threads()
+    # LAPACK's SVD does not scale past a few cores (128 threads are SLOWER than 16 on the GPU box's host):
+    # use the one-GPU CPU share
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
     torch.manual_seed(42)
     state = O.SelectorState.create(shape.points, shape.d_s, shape.d_t)
     crit = torch.nn.CrossEntropyLoss(label_smoothing=LABEL_SMOOTHING[cfg])
@@ -107,7 +109,7 @@ def main() -> None:
     ap.add_argument("--contiguous", action="store_true", help="contiguous inputs instead of the callers' strided views")
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point time table to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=32)
+    ap.add_argument("--cpu-sample-batch", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,14 +130,14 @@ def main() -> None:
                             attn_on_device=shape.layers_t > 1)
     leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
     logits = inp.logits.detach().requires_grad_(True)
-    grad_buf = torch.zeros(STUDENT_PARAMS[args.config] + 4, device=device, dtype=torch.float32)
+    bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), device)
     multi_layer = shape.layers_t > 1
 
     def step():
         if multi_layer:      # selector backward for multi-layer teachers is not implemented yet: forward only
             with torch.no_grad():
                 return mod(logits, inp.targets, leaves, inp.teacher, inp.attn)
-        return one_step(mod, inp, leaves, logits, grad_buf, world)
+        return one_step(mod, inp, leaves, logits, bucket)
 
     for _ in range(args.warmup):
         loss = step()
@@ -171,19 +173,23 @@ def main() -> None:
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
-        ab = algorithmic_bytes(shape, batch, 2 if False else 4)
-        # The Procrustes-core Jacobi call is the largest of its launches; the selector's smaller Jacobi calls
-        # (eigen-solves, principal angles) are separate launches of the same entry point.
+        ab = algorithmic_bytes(shape, batch)
+        # Dominant kernel: jacobi_block_round_kernel, the per-round launch of the block Jacobi eigen-solver
+        # (all 2L + E symmetric D_s x D_s eigen-problems of a step in one entry-point call).  That call is the
+        # longest basd_jacobi_onesided span of every step; it issues MAX_SWEEPS * (nblk - 1) launches.
         spans = sorted(per_call.get(dominant, [0.0]))
         calls_per_step = max(1, len(spans) // max(1, args.steps))
-        core = spans[-args.steps:] if len(spans) >= args.steps else spans
-        core_ms = sum(core) / max(1, len(core))
-        # algorithmic bytes of that launch: the stacked (2n x n) fp32 factors of every (layer, sample) read and
-        # written once, plus n singular values out
-        n = min(shape.n_s, shape.n_t)
-        units = shape.points * batch
-        core_bytes = units * (2 * (2 * n * n * 4) + n * 4)
-        achieved = core_bytes / (core_ms * 1e-3) / 1e9 if core_ms > 0 else 0.0
+        eig = spans[-args.steps:] if len(spans) >= args.steps else spans
+        eig_ms = sum(eig) / max(1, len(eig))
+        d_s = shape.d_s
+        nblk = ((d_s + 15) // 16 + 1) // 2 * 2
+        launches = ops.MAX_SWEEPS * (nblk - 1) if d_s * (d_s + 4) * 4 > 156 * 1024 else 1
+        n_mats = 2 * shape.layers_t + shape.points
+        # algorithmic bytes of the solve: every Gram matrix read once, its rotated image written once
+        solve_bytes = n_mats * 2 * d_s * d_s * 4
+        launch_ms = eig_ms / launches
+        launch_bytes = solve_bytes / launches
+        achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         line = {
             "metric": "distillation images/sec (BASD loss fwd+bwd+grad all-reduce), DeiT-S<-ResNet-50 @ bs256/GPU"
             if args.config == "cfg2" else f"distillation images/sec (BASD loss), {shape.name}",
@@ -206,7 +212,7 @@ def main() -> None:
                 "teacher_tokens": [shape.layers_t, batch, shape.n_t, shape.d_t],
                 "layout": "contiguous" if args.contiguous else "strided (CLS-sliced / channel-major views)",
                 "backward": not multi_layer,
-                "grad_allreduce_bytes": int(grad_buf.numel() * 4) if world > 1 else 0,
+                "grad_allreduce_bytes": int(bucket.buffer.numel() * 4) if world > 1 else 0,
                 "parallelism": f"dp{world}",
             },
             "path_hbm": {
@@ -215,11 +221,12 @@ def main() -> None:
                 "frac_of_8TBps": ab["step"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             "roofline": {
-                "kernel": "jacobi_lds_kernel (one-sided Jacobi SVD of the stacked Procrustes cores)",
+                "kernel": "jacobi_block_round_kernel (block one-sided Jacobi, symmetric eigen-solves of the selector)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "launch_ms": core_ms, "launches_per_step_of_entry_point": calls_per_step,
-                "algorithmic_bytes_per_launch": core_bytes,
+                "launch_ms": launch_ms, "launches_per_step": launches, "solve_ms_per_step": eig_ms,
+                "algorithmic_bytes_per_launch": launch_bytes,
+                "note": "latency-bound chain of dependent pair-steps, not an HBM stream (DESIGN.md section 5)",
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -72,10 +72,11 @@ int basd_jacobi_workspace_ints(int batch, int max_sweeps);
  * right rotations orthogonalise the first rows_dot rows; colnorm receives the column norms.
  * replaces the LAPACK calls behind torch.linalg.eigvalsh (layer_selector.py:16), torch.linalg.svd
  * (:36, :92), torch.linalg.svdvals (:99) and torch.linalg.matrix_norm(ord="nuc") (relational.py:48).
- * n_arr (nullable): per-matrix order for square problems.  flags: basd_jacobi_workspace_ints() ints. */
+ * n_arr (nullable): per-matrix order for square problems.  flags: basd_jacobi_workspace_ints() ints.
+ * tol_cos: stop when every pair has |cos| <= tol_cos over a full sweep (<= 0: eps * sqrt(rows_dot)). */
 int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot, int n, int batch,
-                         const int* n_arr, float* colnorm, int colnorm_stride, int max_sweeps, int* flags,
-                         int* sweeps_out, hipStream_t stream);
+                         const int* n_arr, float* colnorm, int colnorm_stride, int max_sweeps, float tol_cos,
+                         int* flags, int* sweeps_out, hipStream_t stream);
 
 /* Sort column norms descending; optionally emit the top-kmax normalised columns as rows
  * (`Vt[:k]` of layer_selector.py:37, :97). */

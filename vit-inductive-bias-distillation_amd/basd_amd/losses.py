@@ -204,56 +204,70 @@ class GrassmannianLayerSelector(nn.Module):
             self.subspace_ranks[k] = int(r)
 
     # ---- distances + mixing weights ------------------------------------------------------
-    def _distances(self, students: list[torch.Tensor], keys: list[int], teachers: list[torch.Tensor]) -> torch.Tensor:
-        """d_grass_sq (E, L) (layer_selector.py:86-105).  Refreshes ``subspace_ranks``."""
-        with torch.no_grad():
-            d_s = self.student_dim
-            E, L = len(students), len(teachers)
-            dev = students[0].device
-            g_u, g_c, M = self._teacher_grams(teachers)
-            same = g_u.shape[1] == d_s
-            # every symmetric eigen-problem of the step goes through ONE solver call:
-            # [teacher uncentred (L) | teacher centred (L) | student centred (E)]
-            stack = torch.empty(((2 * L if same else L) + E, d_s, d_s), device=dev, dtype=torch.float32)
-            o_c = L if same else 0
-            if same:
-                stack[:L] = g_u
-            stack[o_c:o_c + L] = g_c
-            for e, x in enumerate(students):
-                x = ops.as_supported(x)
-                mean = ops.colmean(x)
-                # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
-                # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
-                stack[o_c + L + e] = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
-            colnorm = ops.jacobi_onesided(stack, d_s)
-            if same:
-                vals_u, _ = ops.sort_extract(stack[:L], colnorm[:L], 0)
-            else:
-                vals_u, _, _, _ = ops.sym_eig(g_u)
-            ranks_dev = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
-            ranks = [int(r) for r in ranks_dev.tolist()]               # the step's single D2H sync
-            for k, r in zip(keys, ranks):
-                self.subspace_ranks[k] = r
-            if min(ranks) == 0:
-                # reference: 0/0 distance -> NaN weights -> NaN tokens -> torch.linalg.svd raises
-                raise torch.linalg.LinAlgError(
-                    "linalg.svd: The algorithm failed to converge because the input matrix contained "
-                    "non-finite values (a teacher layer has Marchenko-Pastur rank 0).")
-            kmax = max(ranks)
-            vals_c, u_t = ops.sort_extract(stack[o_c:o_c + L], colnorm[o_c:o_c + L], kmax)   # (L, kmax, d_s)
-            sw = ops.sqrt_clamp(vals_c[:, :kmax])                      # singular values S[:k]   (:36-37)
-            _, v_s = ops.sort_extract(stack[o_c + L:], colnorm[o_c + L:], kmax)   # (E, kmax, d_s) = Vt_s[:kmax]
-            proj_s_t = self.proj_s.float().t().contiguous()
-            u_rot = ops.gemm_nt(u_t.view(L * kmax, d_s), proj_s_t).view(L, kmax, d_s)   # rows: (proj_s^T u)^T
-            cos = torch.empty((E, L, kmax, kmax), device=dev, dtype=torch.float32)
-            for e in range(E):
-                ops.gemm_nt(v_s[e], u_rot[0], out=cos[e], batch=L, a_batch_stride=0, b_batch_stride=kmax * d_s,
-                            rows=kmax, n_cols=kmax)                    # Vt_s[:k] @ U_t   (:99)
-            k_arr = ranks_dev.repeat(E).contiguous()
-            sigma = ops.jacobi_onesided(cos.view(E * L, kmax, kmax), kmax, n_arr=k_arr)
-            sw_index = torch.arange(L, device=dev, dtype=torch.int32).repeat(E).contiguous()
-            d = ops.grassmann_distance(sigma, k_arr, sw, sw_index)     # (:100-105)
+    @torch.no_grad()
+    def _spectra_async(self, students: list[torch.Tensor], teachers: list[torch.Tensor]) -> dict:
+        """Queue every Gram matrix and eigen-solve of the step on the current stream; no host sync.
+        (layer_selector.py:69-74, :131-138, :86-92)"""
+        d_s = self.student_dim
+        E, L = len(students), len(teachers)
+        dev = students[0].device
+        g_u, g_c, M = self._teacher_grams(teachers)
+        same = g_u.shape[1] == d_s
+        # every symmetric eigen-problem of the step goes through ONE solver call:
+        # [teacher uncentred (L) | teacher centred (L) | student centred (E)]
+        stack = torch.empty(((2 * L if same else L) + E, d_s, d_s), device=dev, dtype=torch.float32)
+        o_c = L if same else 0
+        if same:
+            stack[:L] = g_u
+        stack[o_c:o_c + L] = g_c
+        for e, x in enumerate(students):
+            x = ops.as_supported(x)
+            mean = ops.colmean(x)
+            # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
+            # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
+            stack[o_c + L + e] = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
+        colnorm = ops.jacobi_onesided(stack, d_s)
+        if same:
+            vals_u, _ = ops.sort_extract(stack[:L], colnorm[:L], 0)
+        else:
+            vals_u, _, _, _ = ops.sym_eig(g_u)
+        ranks_dev = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
+        return dict(stack=stack, colnorm=colnorm, ranks_dev=ranks_dev, o_c=o_c, E=E, L=L)
+
+    @torch.no_grad()
+    def _angles_from_spectra(self, st: dict, keys: list[int]) -> torch.Tensor:
+        """The step's single D2H read-back (ranks), then principal angles -> d_grass_sq (E, L)
+        (layer_selector.py:95-105).  Refreshes ``subspace_ranks``."""
+        d_s = self.student_dim
+        stack, colnorm, ranks_dev, o_c, E, L = (st[k] for k in ("stack", "colnorm", "ranks_dev", "o_c", "E", "L"))
+        dev = stack.device
+        ranks = [int(r) for r in ranks_dev.tolist()]
+        for k, r in zip(keys, ranks):
+            self.subspace_ranks[k] = r
+        if min(ranks) == 0:
+            # reference: 0/0 distance -> NaN weights -> NaN tokens -> torch.linalg.svd raises
+            raise torch.linalg.LinAlgError(
+                "linalg.svd: The algorithm failed to converge because the input matrix contained "
+                "non-finite values (a teacher layer has Marchenko-Pastur rank 0).")
+        kmax = max(ranks)
+        vals_c, u_t = ops.sort_extract(stack[o_c:o_c + L], colnorm[o_c:o_c + L], kmax)   # (L, kmax, d_s)
+        sw = ops.sqrt_clamp(vals_c[:, :kmax])                      # singular values S[:k]   (:36-37)
+        _, v_s = ops.sort_extract(stack[o_c + L:], colnorm[o_c + L:], kmax)   # (E, kmax, d_s) = Vt_s[:kmax]
+        proj_s_t = self.proj_s.float().t().contiguous()
+        u_rot = ops.gemm_nt(u_t.view(L * kmax, d_s), proj_s_t).view(L, kmax, d_s)   # rows: (proj_s^T u)^T
+        cos = torch.empty((E, L, kmax, kmax), device=dev, dtype=torch.float32)
+        for e in range(E):
+            ops.gemm_nt(v_s[e], u_rot[0], out=cos[e], batch=L, a_batch_stride=0, b_batch_stride=kmax * d_s,
+                        rows=kmax, n_cols=kmax)                    # Vt_s[:k] @ U_t   (:99)
+        k_arr = ranks_dev.repeat(E).contiguous()
+        sigma = ops.jacobi_onesided(cos.view(E * L, kmax, kmax), kmax, n_arr=k_arr)
+        sw_index = torch.arange(L, device=dev, dtype=torch.int32).repeat(E).contiguous()
+        d = ops.grassmann_distance(sigma, k_arr, sw, sw_index)     # (:100-105)
         return d.view(E, L)
+
+    def _distances(self, students: list[torch.Tensor], keys: list[int], teachers: list[torch.Tensor]) -> torch.Tensor:
+        """d_grass_sq (E, L) (layer_selector.py:86-105)."""
+        return self._angles_from_spectra(self._spectra_async(students, teachers), keys)
 
     def mixing_weights(self, students: list[torch.Tensor], keys: list[int],
                        teachers: list[torch.Tensor]) -> torch.Tensor:
@@ -321,6 +335,13 @@ class BASDLoss(nn.Module):
             teacher_dim=teacher_dim,
         )
         self.last_components: dict[str, torch.Tensor] = {}
+        self._side_streams: dict = {}
+
+    def _selector_stream(self, device) -> "torch.cuda.Stream":
+        key = str(device)
+        if key not in self._side_streams:
+            self._side_streams[key] = torch.cuda.Stream(device=device)
+        return self._side_streams[key]
 
     @torch.compiler.disable
     def forward(
@@ -345,8 +366,25 @@ class BASDLoss(nn.Module):
         if len(keys) > 1 and torch.is_grad_enabled() and any(s.requires_grad for s in students):
             raise NotImplementedError("selector backward for multi-layer teachers is not implemented yet")
 
-        mix = self.layer_selector.mixing_weights(students, keys, teachers)
-        geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
+        sel = self.layer_selector
+        if len(keys) == 1:
+            # One teacher layer (CNN teachers): softmax over a single distance is 1 whatever the distance, so
+            # the Procrustes loss does not depend on the selector.  The selector's eigen-solves are latency-
+            # bound chains of small launches; run them on a side stream underneath the Procrustes kernels.
+            main = torch.cuda.current_stream()
+            side = self._selector_stream(main.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                spectra = sel._spectra_async(students, teachers)
+            tau = sel.temperatures.float()
+            mix = torch.softmax(torch.zeros((len(students), 1), device=tau.device) / tau.unsqueeze(1), dim=1)
+            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
+            with torch.cuda.stream(side):
+                sel._angles_from_spectra(spectra, keys)    # host reads the ranks; raises on rank 0 like the reference
+            main.wait_stream(side)
+        else:
+            mix = sel.mixing_weights(students, keys, teachers)
+            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
         geo_loss = geo_layers.mean()
 
         vals = [ce_loss, geo_loss]

@@ -114,7 +114,7 @@ def colmean(x: torch.Tensor) -> torch.Tensor:
 # Jacobi solver
 # --------------------------------------------------------------------------- #
 def jacobi_onesided(W: torch.Tensor, rows_dot: int, *, n_arr: torch.Tensor | None = None,
-                    want_sweeps: bool = False):
+                    want_sweeps: bool = False, tol: float = 0.0):
     """In-place one-sided Jacobi on W: (batch, n, rows_tot) memory == column-major (rows_tot x n).
     Returns column norms (batch, n) [and the sweep counts]."""
     _require_cuda(W)
@@ -125,7 +125,7 @@ def jacobi_onesided(W: torch.Tensor, rows_dot: int, *, n_arr: torch.Tensor | Non
                         dtype=torch.int32)
     sweeps = torch.zeros((batch,), device=W.device, dtype=torch.int32) if want_sweeps else None
     _lib.call("basd_jacobi_onesided", W.data_ptr(), n * rows_tot, rows_dot, rows_tot, n, batch, _ptr(n_arr),
-              colnorm.data_ptr(), n, MAX_SWEEPS, flags.data_ptr(), _ptr(sweeps), _stream())
+              colnorm.data_ptr(), n, MAX_SWEEPS, tol, flags.data_ptr(), _ptr(sweeps), _stream())
     return (colnorm, sweeps) if want_sweeps else colnorm
 
 

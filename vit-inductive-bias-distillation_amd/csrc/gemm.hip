@@ -330,14 +330,19 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(GemmOperand X, int 
         partial[((long)blockIdx.z * parts + blockIdx.y) * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int cols, int parts, float inv_rows,
-                                    float* __restrict__ mean) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int cols, int parts,
+                                                           float inv_rows, float* __restrict__ mean) {
+    // block = 64 columns x 4 part groups (fixed summation order: deterministic)
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     const float* p = partial + (long)blockIdx.y * parts * cols;
     float s = 0.f;
-    for (int k = 0; k < parts; ++k) s += p[(long)k * cols + c];
-    mean[(long)blockIdx.y * cols + c] = s * inv_rows;
+    if (c < cols)
+        for (int k = pg; k < parts; k += 4) s += p[(long)k * cols + c];
+    red[pg][cl] = s;
+    __syncthreads();
+    if (pg == 0 && c < cols)
+        mean[(long)blockIdx.y * cols + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) * inv_rows;
 }
 
 }  // namespace basd
@@ -434,7 +439,7 @@ int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_p
     if (dtype == BASD_DTYPE_F32) colsum_partial_kernel<float><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial);
     else if (dtype == BASD_DTYPE_BF16) colsum_partial_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial);
     else return BASD_EINVAL;
-    colsum_final_kernel<<<dim3((cols + 255) / 256, batch), 256, 0, stream>>>(partial, cols, parts, 1.f / rows, mean);
+    colsum_final_kernel<<<dim3((cols + 63) / 64, batch), 256, 0, stream>>>(partial, cols, parts, 1.f / rows, mean);
     BASD_RETURN_LAST();
 }
 

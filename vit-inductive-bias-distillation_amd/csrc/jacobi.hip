@@ -102,32 +102,35 @@ __device__ __forceinline__ float pair_allsum(float x) {
 // null2: columns whose squared norm is below it are numerically null (sigma < 4 eps sigma_max, measured in
 // the previous sweep); they are pure round-off, never become "orthogonal relative to their own size", and
 // would keep the sweep loop alive for ever, so pairs involving them count as converged.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int EPL, int DOT, int LPP>
 __device__ __forceinline__ bool rotate_pair(float* __restrict__ cp, float* __restrict__ cq, int gl, float tol,
                                             float null2, float& norm2_max, float* __restrict__ n2p,
                                             float* __restrict__ n2q, float* __restrict__ devp,
                                             float* __restrict__ devq) {
-    float x[EPL], y[EPL];
-    float g0 = 0.f, g1 = 0.f;
+    // lane gl owns the row pairs (2 gl, 2 gl + 1) + 2 LPP i: 8-byte LDS accesses and packed fp32 math
+    static_assert(EPL % 2 == 0 && DOT % 2 == 0, "row chunks come in pairs");
+    constexpr int H = EPL / 2;
+    f32x2 x[H], y[H];
+    f32x2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-        x[i] = cp[gl + LPP * i];
-        y[i] = cq[gl + LPP * i];
-        if (i < DOT) {
-            if (i & 1) g1 = fmaf(x[i], y[i], g1);
-            else g0 = fmaf(x[i], y[i], g0);
-        }
+    for (int i = 0; i < H; ++i) {
+        x[i] = *(const f32x2*)(cp + 2 * gl + 2 * LPP * i);
+        y[i] = *(const f32x2*)(cq + 2 * gl + 2 * LPP * i);
+        if (2 * i < DOT) acc = __builtin_elementwise_fma(x[i], y[i], acc);
     }
-    const float g = pair_allsum<LPP>(g0 + g1);
+    const float g = pair_allsum<LPP>(acc.x + acc.y);
     const float a = *n2p, b = *n2q;
     norm2_max = fmaxf(norm2_max, fmaxf(a, b));
     if (fminf(a, b) <= null2) return false;
-    const Rot rot = make_rotation(a, b, g, tol);   // identical in every lane of the row
+    const Rot rot = make_rotation(a, b, g, tol);   // identical in every lane of the group
     if (!rot.apply) return false;
+    const f32x2 c2 = {rot.c, rot.c}, s2 = {rot.s, rot.s};
 #pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-        cp[gl + LPP * i] = fmaf(rot.c, x[i], -rot.s * y[i]);
-        cq[gl + LPP * i] = fmaf(rot.s, x[i], rot.c * y[i]);
+    for (int i = 0; i < H; ++i) {
+        *(f32x2*)(cp + 2 * gl + 2 * LPP * i) = __builtin_elementwise_fma(c2, x[i], -(s2 * y[i]));
+        *(f32x2*)(cq + 2 * gl + 2 * LPP * i) = __builtin_elementwise_fma(s2, x[i], c2 * y[i]);
     }
     if (gl == 0) {
         *n2p = fmaxf(a - rot.t * g, 0.f);
@@ -138,13 +141,16 @@ __device__ __forceinline__ bool rotate_pair(float* __restrict__ cp, float* __res
     return true;
 }
 
-// exact squared norm (over the dot rows) of one padded LDS column, by one DPP row
+// exact squared norm (over the dot rows) of one padded LDS column, by one lane group
 template <int DOT, int LPP>
 __device__ __forceinline__ float column_norm2(const float* __restrict__ col, int gl) {
-    float a = 0.f;
+    f32x2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < DOT; ++i) a = fmaf(col[gl + LPP * i], col[gl + LPP * i], a);
-    return pair_allsum<LPP>(a);
+    for (int i = 0; i < DOT / 2; ++i) {
+        const f32x2 v = *(const f32x2*)(col + 2 * gl + 2 * LPP * i);
+        acc = __builtin_elementwise_fma(v, v, acc);
+    }
+    return pair_allsum<LPP>(acc.x + acc.y);
 }
 
 // LDS row of global row r: dot rows first, the riding rows start at the next multiple of 16
@@ -162,7 +168,7 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
                                                            int rows_tot, int n_fixed, const int* __restrict__ n_arr,
                                                            int max_sweeps, float tol, float* __restrict__ colnorm,
                                                            int colnorm_stride, int* __restrict__ sweeps_out) {
-    constexpr int LD = 16 * EPL + 1;
+    constexpr int LD = 16 * EPL + 2;   // even: 8-byte aligned columns for the paired accesses
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m = blockIdx.x;
     int n = n_arr ? n_arr[m] : n_fixed;
@@ -251,7 +257,7 @@ __global__ void __launch_bounds__(64 * BW) jacobi_block_round_kernel(float* __re
                                                                      float tol, int* __restrict__ flags,
                                                                      int* __restrict__ norm2_bits) {
     constexpr int LPP = 64;
-    constexpr int LD = LPP * EPL + 1;
+    constexpr int LD = LPP * EPL + 2;   // even: 8-byte aligned columns for the paired accesses
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m = blockIdx.y;
     if (sweep > 0 && flags[m * max_sweeps + sweep - 1] == 0) return;  // converged in an earlier sweep
@@ -444,11 +450,14 @@ int basd_jacobi_workspace_ints(int batch, int max_sweeps) { return 2 * batch * m
 //   colnorm: (batch, colnorm_stride) column norms over the first rows_dot rows.
 //   flags: device scratch of basd_jacobi_workspace_ints() ints (block path only, may be null
 //   when the LDS path is taken).
+//   tol_cos: stop once every pair has |cos| <= tol_cos in a full sweep (<= 0: eps * sqrt(rows_dot)).  Column
+//   norms (singular / eigen values) are second-order accurate in it, vectors first-order.
 int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot, int n, int batch,
-                         const int* n_arr, float* colnorm, int colnorm_stride, int max_sweeps, int* flags,
-                         int* sweeps_out, hipStream_t stream) {
+                         const int* n_arr, float* colnorm, int colnorm_stride, int max_sweeps, float tol_cos,
+                         int* flags, int* sweeps_out, hipStream_t stream) {
     BASD_CHECK_ARG(W && colnorm && rows_dot > 0 && rows_tot >= rows_dot && n > 0 && batch > 0 && max_sweeps > 0);
-    const float tol = 1.2e-7f * sqrtf((float)rows_dot);
+    // a pair counts as orthogonal when |cos| <= tol; <= 0 selects the round-off level eps * sqrt(rows)
+    const float tol = tol_cos > 0.f ? tol_cos : 1.2e-7f * sqrtf((float)rows_dot);
     const int n_even = (n + 1) & ~1;
     // per-lane element counts of the zero-padded LDS columns (16 lanes per column pair)
     const bool stacked = rows_tot > rows_dot;
@@ -461,9 +470,9 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
     static const int lds_epl[] = {2, 4, 6, 8, 12, 16, 20};
     int e_lds = 0;
     for (int e : lds_epl)
-        if (e >= epl && (!stacked || e % 2 == 0)) { e_lds = e; break; }
-    if (e_lds && (size_t)n_even * (16 * e_lds + 3) * sizeof(float) <= BASD_JACOBI_LDS_LIMIT) {
-        const size_t lds_bytes = (size_t)n_even * (16 * e_lds + 3) * sizeof(float);
+        if (e >= epl && (!stacked || e % 4 == 0)) { e_lds = e; break; }
+    if (e_lds && (size_t)n_even * (16 * e_lds + 4) * sizeof(float) <= BASD_JACOBI_LDS_LIMIT) {
+        const size_t lds_bytes = (size_t)n_even * (16 * e_lds + 4) * sizeof(float);
         // every pair of a round-robin round in flight at once when it fits the block
         int threads = (((n_even / 2) * 16 + 63) / 64) * 64;
         if (threads > 1024) threads = 1024;
@@ -476,10 +485,13 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
                                                                         n_arr, max_sweeps, tol, colnorm,           \
                                                                         colnorm_stride, sweeps_out);               \
     } while (0)
-#define LAUNCH_LDS_E(E)                 \
-    do {                                \
-        if (stacked) LAUNCH_LDS(E, E / 2); \
-        else LAUNCH_LDS(E, E);          \
+#define LAUNCH_LDS_E(E)                                      \
+    do {                                                     \
+        if (stacked) {                                       \
+            if constexpr ((E) % 4 == 0) LAUNCH_LDS(E, (E) / 2); \
+        } else {                                             \
+            LAUNCH_LDS(E, E);                                \
+        }                                                    \
     } while (0)
         switch (e_lds) {
             case 2: LAUNCH_LDS_E(2); break;
@@ -507,9 +519,9 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
     static const int blk_epl[] = {2, 4, 6, 8, 12, 16};
     int e_blk = 0;
     for (int e : blk_epl)
-        if (e >= epl64) { e_blk = e; break; }
+        if (e >= epl64 && (!stacked || e % 4 == 0)) { e_blk = e; break; }
     if (!e_blk) return BASD_EUNSUPPORTED;                        // more than 1024 (padded) rows
-    const size_t panel_bytes = (size_t)2 * BW * (64 * e_blk + 3) * sizeof(float);
+    const size_t panel_bytes = (size_t)2 * BW * (64 * e_blk + 4) * sizeof(float);
     if (panel_bytes > BASD_JACOBI_LDS_LIMIT) return BASD_EUNSUPPORTED;
     hipError_t err = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)2 * batch * max_sweeps, stream);
     if (err != hipSuccess) return (int)err;
@@ -524,10 +536,13 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
                     W, batch_stride, rows_dot, rows_tot, n, nblk, r, s, max_sweeps, tol, flags,                  \
                     flags + (size_t)batch * max_sweeps);                                                         \
     } while (0)
-#define LAUNCH_BLOCK_E(E)                    \
-    do {                                     \
-        if (stacked) LAUNCH_BLOCK(E, E / 2); \
-        else LAUNCH_BLOCK(E, E);             \
+#define LAUNCH_BLOCK_E(E)                                      \
+    do {                                                       \
+        if (stacked) {                                         \
+            if constexpr ((E) % 4 == 0) LAUNCH_BLOCK(E, (E) / 2); \
+        } else {                                               \
+            LAUNCH_BLOCK(E, E);                                \
+        }                                                      \
     } while (0)
     switch (e_blk) {
         case 2: LAUNCH_BLOCK_E(2); break;
