@@ -134,9 +134,6 @@ def main() -> None:
     multi_layer = shape.layers_t > 1
 
     def step():
-        if multi_layer:      # selector backward for multi-layer teachers is not implemented yet: forward only
-            with torch.no_grad():
-                return mod(logits, inp.targets, leaves, inp.teacher, inp.attn)
         return one_step(mod, inp, leaves, logits, bucket)
 
     for _ in range(args.warmup):
@@ -211,7 +208,7 @@ def main() -> None:
                 "student_tokens": [shape.points, batch, shape.n_s, shape.d_s],
                 "teacher_tokens": [shape.layers_t, batch, shape.n_t, shape.d_t],
                 "layout": "contiguous" if args.contiguous else "strided (CLS-sliced / channel-major views)",
-                "backward": not multi_layer,
+                "backward": True,
                 "grad_allreduce_bytes": int(bucket.buffer.numel() * 4) if world > 1 else 0,
                 "parallelism": f"dp{world}",
             },

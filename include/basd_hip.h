@@ -34,7 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 
 /* ---- dense contractions (fp32 MFMA, v_mfma_f32_32x32x2_f32) ------------------------------- */
 
-/* C[z] (M x N, ldc) = scale * A[z] (M x K) * B[z]^T (N x K).
+/* C[z] (M x N, ldc) = beta * C[z] + scale * A[z] (M x K) * B[z]^T (N x K) - 1 bias^T   (bias nullable).
  * replaces: `tokens.reshape(-1, D_t) @ proj_t.T`  layer_selector.py:72,:135;
  *           `features @ features.T / M`           layer_selector.py:15;
  *           `U_s.T @ U_t`                          layer_selector.py:99.
@@ -42,7 +42,8 @@ typedef struct ihipStream_t* hipStream_t;
  * (so (B, N, D) token views, CLS-sliced or channel-major, are consumed in place). B: fp32 row-major. */
 int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, int a_rows_per_batch,
                  long a_batch_stride, const float* b, long ldb, long b_batch_stride, int M, int N, int K, int batch,
-                 float* c, long ldc, long c_batch_stride, float scale, hipStream_t stream);
+                 float* c, long ldc, long c_batch_stride, float scale, const float* bias, float beta,
+                 hipStream_t stream);
 
 /* Suggested split count over the contraction rows for basd_gemm_tn. */
 int basd_gemm_tn_splits(int krows);
@@ -147,7 +148,43 @@ int basd_procrustes_finalize(const float* w, long w_batch_stride, const float* s
  * with respect to the student tokens. */
 int basd_student_grad(const void* x, int dtype, long sb, long sn, int B, int n_s, int n_t, int D, const float* omega,
                       const float* mu, const float* h, const int* tap0, const int* tap1, const float* lam,
-                      const float* scale_ptr, float scale_const, float* dx, hipStream_t stream);
+                      const float* scale_ptr, float scale_const, float* dx, const float* tnorm2, float* gomega,
+                      hipStream_t stream);
+
+/* ---- multi-layer teachers only: gradients through the mixing weights and the principal angles ------ */
+
+/* Kt = Q - K'' with d loss_b / d T_c = 2 Kt T_c (autograd of relational.py:36-50 w.r.t. the mixed teacher
+ * tokens of layer_selector.py:111), and |t_hat_c[s]|^2 per student token. */
+int basd_teacher_factor(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
+                        const double* la, const double* gb, long g_batch_stride, const float* omega,
+                        const int* tap0, const int* tap1, const float* lam, const int* range0, const int* range1,
+                        float* kt, float* tnorm2, hipStream_t stream);
+
+/* partial[e][b][l] = <R[e][b], teacher layer l on the core grid>: d loss / d mix_l through the tokens
+ * (layer_selector.py:111). */
+int basd_mix_grad_tokens(const float* r, const void* const* tok_ptrs, int dtype, int L, long sb, long sn, long sd,
+                         int E, int B, int n, int D, const int* g0, const int* g1, const float* glam, float* partial,
+                         hipStream_t stream);
+
+/* partial[e][b][l] = d loss / d mix_l through the attention-derived token weights
+ * (layer_selector.py:112 + relational.py:22-34). */
+int basd_token_weight_bwd(const float* gomega, const float* raw, int E, int B, int n_a, int n_s, const int* atap0,
+                          const int* atap1, const float* alam, const int* arange0, const int* arange1,
+                          const void* const* attn_ptrs, int dtype, int L, long sb, long sh, long sq, long sk, int H,
+                          int A, int has_cls, float* partial, hipStream_t stream);
+
+/* [masked cosine matrix ; identity] stacks (2 kmax x kmax, column-major) for the principal-angle SVD with
+ * right singular vectors (backward of layer_selector.py:99). */
+int basd_build_angle_stack(const float* cos, int kmax, const int* k_arr, int items, float* out, hipStream_t stream);
+
+/* gWt[item][j][i] = d (d_grass_sq[item]) / d W[i][j] * gd[item]  (backward of layer_selector.py:99-105). */
+int basd_grassmann_distance_bwd(const float* stack, const float* colnorm, int kmax, const int* k_arr, const float* sw,
+                                int sw_stride, const int* sw_index, const float* gd, int items, float* gwt,
+                                hipStream_t stream);
+
+/* K2[i][j] = (M[i][j] - M[j][i]) / (lam_j - lam_i): eigenvector perturbation of the student Gram
+ * (backward of torch.linalg.svd at layer_selector.py:92). */
+int basd_eigvec_k2(const float* m, const float* lam, int D, int kmax, int batch, float* k2, hipStream_t stream);
 
 /* Stand-alone `_align_token_count` (combined.py:9-14): out (B, n_out, D) fp32 contiguous; and its adjoint. */
 int basd_resample_tokens(const void* x, int dtype, long sb, long sn, long sd, int B, int n_in, int n_out, int D,

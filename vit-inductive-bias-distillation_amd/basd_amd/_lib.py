@@ -16,7 +16,8 @@ vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
 # name -> argtypes (return type is always int)
 SIGNATURES = {
-    "basd_gemm_nt": [vp, i32, i64, i64, i64, i32, i64, vp, i64, i64, i32, i32, i32, i32, vp, i64, i64, f32, vp],
+    "basd_gemm_nt": [vp, i32, i64, i64, i64, i32, i64, vp, i64, i64, i32, i32, i32, i32, vp, i64, i64, f32, vp, f32,
+                     vp],
     "basd_gemm_tn_splits": [i32],
     "basd_gemm_tn": [vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp,
                      vp, i64, i64, f32, vp],
@@ -39,7 +40,14 @@ SIGNATURES = {
                                  vp],
     "basd_resample_tokens": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "basd_resample_tokens_adjoint": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
-    "basd_student_grad": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp],
+    "basd_student_grad": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp],
+    "basd_teacher_factor": [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "basd_mix_grad_tokens": [vp, vp, i32, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "basd_token_weight_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, i64, i32,
+                              i32, i32, vp, vp],
+    "basd_build_angle_stack": [vp, i32, vp, i32, vp, vp],
+    "basd_grassmann_distance_bwd": [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp],
+    "basd_eigvec_k2": [vp, vp, i32, i32, i32, vp, vp],
 }
 
 _lock = threading.Lock()

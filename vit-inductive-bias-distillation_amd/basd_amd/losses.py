@@ -105,28 +105,63 @@ class _ProcrustesLayers(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mix, has_cls, teachers, attns, *students):
         need_bwd = any(s.requires_grad for s in students)
-        pc = ops.procrustes_forward(list(students), teachers, attns, mix.detach(), has_cls, need_backward=need_bwd)
+        # one teacher layer: softmax over one logit is constant, d loss / d mix is exactly 0
+        need_mix = bool(mix.requires_grad and mix.shape[1] > 1)
+        pc = ops.procrustes_forward(list(students), teachers, attns, mix.detach(), has_cls,
+                                    need_backward=need_bwd or need_mix, need_mix_grad=need_mix)
         ctx.pc = pc
         ctx.n_students = len(students)
         ctx.save_for_backward(*students)
-        ctx.mix_needs_grad = mix.requires_grad and mix.shape[1] > 1
+        ctx.need_mix = need_mix
         ctx.mix_shape = tuple(mix.shape)
         return pc.loss_b.mean(dim=1)
 
     @staticmethod
     def backward(ctx, grad_layers):
         students = ctx.saved_tensors
-        if ctx.mix_needs_grad:
-            raise NotImplementedError(
-                "gradient through the layer-mixing weights (multi-layer teachers) is not implemented yet")
-        # a single teacher layer: softmax over one logit is constant, so d loss / d mix is exactly 0
-        g_mix = torch.zeros(ctx.mix_shape, device=grad_layers.device) if ctx.needs_input_grad[0] else None
-        if ctx.pc.k_prime is None:
+        pc = ctx.pc
+        g_mix = None
+        if pc.k_prime is None:
+            if ctx.needs_input_grad[0]:
+                g_mix = torch.zeros(ctx.mix_shape, device=grad_layers.device)
             return (g_mix, None, None, None) + (None,) * ctx.n_students
-        grads = ops.procrustes_student_grads(list(students), ctx.pc, grad_layers)
+        if ctx.need_mix:
+            kt, tnorm2 = ops.procrustes_teacher_factor(pc)
+            grads, gomega = ops.procrustes_student_grads(list(students), pc, grad_layers, tnorm2)
+            g_mix = ops.procrustes_mix_grads(pc, kt, gomega, grad_layers)
+        else:
+            grads = ops.procrustes_student_grads(list(students), pc, grad_layers)
+            if ctx.needs_input_grad[0]:
+                g_mix = torch.zeros(ctx.mix_shape, device=grad_layers.device)
         grads = [g.to(s.dtype) if ctx.needs_input_grad[4 + i] else None
                  for i, (g, s) in enumerate(zip(grads, students))]
         return (g_mix, None, None, None, *grads)
+
+
+class _GrassmannDistance(torch.autograd.Function):
+    """(selector, keys, teachers, *students) -> d_grass_sq (E, L), differentiable w.r.t. the student tokens
+    (reference layer_selector.py:86-105; the backward is the eigenvector-perturbation route)."""
+
+    @staticmethod
+    def forward(ctx, selector, keys, teachers, *students):
+        want_grad = any(s.requires_grad for s in students)
+        spectra = selector._spectra_async(list(students), teachers)
+        d, saved = selector._angles_from_spectra(spectra, keys, want_grad=want_grad)
+        ctx.saved = saved
+        ctx.selector = selector
+        ctx.n_students = len(students)
+        ctx.save_for_backward(*students)
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        students = ctx.saved_tensors
+        if ctx.saved is None:
+            return (None, None, None) + (None,) * ctx.n_students
+        grads = ctx.selector._distance_backward(ctx.saved, list(students), gd)
+        grads = [g.to(s.dtype) if ctx.needs_input_grad[3 + i] else None
+                 for i, (g, s) in enumerate(zip(grads, students))]
+        return (None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------- #
@@ -220,9 +255,11 @@ class GrassmannianLayerSelector(nn.Module):
         if same:
             stack[:L] = g_u
         stack[o_c:o_c + L] = g_c
+        means = []
         for e, x in enumerate(students):
             x = ops.as_supported(x)
             mean = ops.colmean(x)
+            means.append(mean)
             # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
             # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
             stack[o_c + L + e] = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
@@ -232,12 +269,13 @@ class GrassmannianLayerSelector(nn.Module):
         else:
             vals_u, _, _, _ = ops.sym_eig(g_u)
         ranks_dev = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
-        return dict(stack=stack, colnorm=colnorm, ranks_dev=ranks_dev, o_c=o_c, E=E, L=L)
+        return dict(stack=stack, colnorm=colnorm, ranks_dev=ranks_dev, o_c=o_c, E=E, L=L, means=means)
 
     @torch.no_grad()
-    def _angles_from_spectra(self, st: dict, keys: list[int]) -> torch.Tensor:
+    def _angles_from_spectra(self, st: dict, keys: list[int], want_grad: bool = False):
         """The step's single D2H read-back (ranks), then principal angles -> d_grass_sq (E, L)
-        (layer_selector.py:95-105).  Refreshes ``subspace_ranks``."""
+        (layer_selector.py:95-105).  Refreshes ``subspace_ranks``.  Returns (d, saved state for
+        ``_distance_backward`` or None)."""
         d_s = self.student_dim
         stack, colnorm, ranks_dev, o_c, E, L = (st[k] for k in ("stack", "colnorm", "ranks_dev", "o_c", "E", "L"))
         dev = stack.device
@@ -252,22 +290,59 @@ class GrassmannianLayerSelector(nn.Module):
         kmax = max(ranks)
         vals_c, u_t = ops.sort_extract(stack[o_c:o_c + L], colnorm[o_c:o_c + L], kmax)   # (L, kmax, d_s)
         sw = ops.sqrt_clamp(vals_c[:, :kmax])                      # singular values S[:k]   (:36-37)
-        _, v_s = ops.sort_extract(stack[o_c + L:], colnorm[o_c + L:], kmax)   # (E, kmax, d_s) = Vt_s[:kmax]
+        # all eigenvectors are needed by the backward (perturbation couples the kept and the discarded ones)
+        lam_s, v_all = ops.sort_extract(stack[o_c + L:], colnorm[o_c + L:], d_s if want_grad else kmax)
+        v_s = v_all[:, :kmax]                                      # (E, kmax, d_s) rows = Vt_s[:kmax]
         proj_s_t = self.proj_s.float().t().contiguous()
         u_rot = ops.gemm_nt(u_t.view(L * kmax, d_s), proj_s_t).view(L, kmax, d_s)   # rows: (proj_s^T u)^T
         cos = torch.empty((E, L, kmax, kmax), device=dev, dtype=torch.float32)
         for e in range(E):
-            ops.gemm_nt(v_s[e], u_rot[0], out=cos[e], batch=L, a_batch_stride=0, b_batch_stride=kmax * d_s,
+            a = v_s[e] if v_s[e].is_contiguous() else v_s[e].contiguous()
+            ops.gemm_nt(a, u_rot[0], out=cos[e], batch=L, a_batch_stride=0, b_batch_stride=kmax * d_s,
                         rows=kmax, n_cols=kmax)                    # Vt_s[:k] @ U_t   (:99)
         k_arr = ranks_dev.repeat(E).contiguous()
-        sigma = ops.jacobi_onesided(cos.view(E * L, kmax, kmax), kmax, n_arr=k_arr)
         sw_index = torch.arange(L, device=dev, dtype=torch.int32).repeat(E).contiguous()
-        d = ops.grassmann_distance(sigma, k_arr, sw, sw_index)     # (:100-105)
-        return d.view(E, L)
+        if not want_grad:
+            sigma = ops.jacobi_onesided(cos.view(E * L, kmax, kmax), kmax, n_arr=k_arr)
+            return ops.grassmann_distance(sigma, k_arr, sw, sw_index).view(E, L), None   # (:100-105)
+        # with a backward: [cos ; I] stacks so that the solver also delivers the right singular vectors
+        ang = ops.angle_stack(cos.view(E * L, kmax, kmax), k_arr)
+        sigma = ops.jacobi_onesided(ang, kmax)
+        d = ops.grassmann_distance(sigma, k_arr, sw, sw_index).view(E, L)
+        saved = dict(ang=ang, sigma=sigma, k_arr=k_arr, sw=sw, sw_index=sw_index, u_rot=u_rot, v_all=v_all,
+                     lam=lam_s, means=st["means"], kmax=kmax, E=E, L=L)
+        return d, saved
+
+    @torch.no_grad()
+    def _distance_backward(self, sv: dict, students: list[torch.Tensor], gd: torch.Tensor) -> list[torch.Tensor]:
+        """d (sum gd * d_grass_sq) / d student tokens: autograd of layer_selector.py:86-105.
+        svdvals -> (theta, weighted distance) -> Vt_s -> centred student Gram -> tokens."""
+        d_s = self.student_dim
+        E, L, kmax = sv["E"], sv["L"], sv["kmax"]
+        gwt = ops.grassmann_distance_bwd(sv["ang"], sv["sigma"], sv["k_arr"], sv["sw"], sv["sw_index"],
+                                         gd.reshape(E * L).float())                    # (E*L, kmax, kmax)
+        u_flat = sv["u_rot"].view(L * kmax, d_s)
+        m_all = torch.empty((E, d_s, kmax), device=gd.device, dtype=torch.float32)
+        for e in range(E):
+            # G_V^T (kmax x d_s) = sum_l gW_l U_l'^T : contraction over (l, j)
+            gvt = ops.gemm_tn(gwt[e * L:(e + 1) * L].view(L * kmax, kmax), u_flat)
+            m_all[e] = ops.gemm_nt(sv["v_all"][e], gvt)                                 # M = V^T G_V  (d_s x kmax)
+        k2 = ops.eigvec_k2(m_all, sv["lam"])                                            # (E, d_s, d_s), symmetric
+        grads = []
+        for e, x in enumerate(students):
+            v = sv["v_all"][e]
+            y = ops.gemm_tn(k2[e], v)                                                   # K2 V^T-rows
+            q = ops.gemm_tn(v, y)                                                       # Q = V K2 V^T (symmetric)
+            mu = sv["means"][e].view(1, d_s)
+            bias = ops.gemm_nt(mu, q).view(d_s)                                         # mu Q
+            x = ops.as_supported(x)
+            dx = ops.gemm_nt(x, q, bias=bias)                                           # (X - 1 mu^T) Q
+            grads.append(dx.view(x.shape[0], x.shape[1], d_s))
+        return grads
 
     def _distances(self, students: list[torch.Tensor], keys: list[int], teachers: list[torch.Tensor]) -> torch.Tensor:
-        """d_grass_sq (E, L) (layer_selector.py:86-105)."""
-        return self._angles_from_spectra(self._spectra_async(students, teachers), keys)
+        """d_grass_sq (E, L) (layer_selector.py:86-105), differentiable w.r.t. the student tokens."""
+        return _GrassmannDistance.apply(self, keys, teachers, *students)
 
     def mixing_weights(self, students: list[torch.Tensor], keys: list[int],
                        teachers: list[torch.Tensor]) -> torch.Tensor:
@@ -289,8 +364,6 @@ class GrassmannianLayerSelector(nn.Module):
         teachers = ops._check_common_layout([ops.as_supported(all_teacher_tokens[k]) for k in keys],
                                             "teacher token tensors")
         students = [student_tokens_per_layer[s] for s in extraction_indices]
-        if len(keys) > 1 and torch.is_grad_enabled() and any(s.requires_grad for s in students):
-            raise NotImplementedError("selector backward for multi-layer teachers is not implemented yet")
         mix = self.mixing_weights(students, keys, teachers)
         tok_stack = torch.stack([all_teacher_tokens[k] for k in keys])
         att_stack = torch.stack([all_teacher_attns[k] for k in keys])
@@ -363,8 +436,6 @@ class BASDLoss(nn.Module):
         teachers = ops._check_common_layout([ops.as_supported(all_teacher_tokens[k]) for k in keys],
                                             "teacher token tensors")
         attns = [all_teacher_attns[k] for k in keys]
-        if len(keys) > 1 and torch.is_grad_enabled() and any(s.requires_grad for s in students):
-            raise NotImplementedError("selector backward for multi-layer teachers is not implemented yet")
 
         sel = self.layer_selector
         if len(keys) == 1:

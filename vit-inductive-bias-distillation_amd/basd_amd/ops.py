@@ -59,8 +59,8 @@ def _tok3(x: torch.Tensor) -> tuple[int, int, int, int, int, int]:
 # --------------------------------------------------------------------------- #
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, scale: float = 1.0, out: torch.Tensor | None = None,
             a_batch_stride: int = 0, b_batch_stride: int = 0, batch: int = 1, rows: int | None = None,
-            n_cols: int | None = None) -> torch.Tensor:
-    """C = scale * A @ B.T.  A: (B,N,K) or (M,K) view in fp32/bf16; B: (N,K) fp32 row-major.
+            n_cols: int | None = None, bias: torch.Tensor | None = None, beta: float = 0.0) -> torch.Tensor:
+    """C = beta * C + scale * A @ B.T - bias.  A: (B,N,K) or (M,K) view in fp32/bf16; B: (N,K) fp32 row-major.
     With batch > 1, element z uses a/b advanced by the given batch strides."""
     _require_cuda(a, b)
     ptr, dt, sb, sn, sd, rpb = _tok3(a)
@@ -72,7 +72,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, scale: float = 1.0, out: torch.
     if out is None:
         out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=a.device, dtype=torch.float32)
     _lib.call("basd_gemm_nt", ptr, dt, sb, sn, sd, rpb, a_batch_stride, b.data_ptr(), ldb, b_batch_stride,
-              M, N, K, batch, out.data_ptr(), N, M * N, scale, _stream())
+              M, N, K, batch, out.data_ptr(), N, M * N, scale, _ptr(bias), beta, _stream())
     return out
 
 
@@ -238,6 +238,7 @@ class ProcrustesContext:
     nuc: torch.Tensor        # (E, B)
     loss_b: torch.Tensor     # (E, B)
     sweeps: torch.Tensor | None
+    mixgrad: dict | None = None   # extra state kept only when the mixing weights need a gradient
 
 
 def _check_common_layout(tensors: list[torch.Tensor], what: str) -> list[torch.Tensor]:
@@ -256,7 +257,7 @@ def _check_common_layout(tensors: list[torch.Tensor], what: str) -> list[torch.T
 
 def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor], attns: list[torch.Tensor],
                        mix: torch.Tensor, has_cls: bool, *, need_backward: bool = True,
-                       want_sweeps: bool = False) -> ProcrustesContext:
+                       want_sweeps: bool = False, need_mix_grad: bool = False) -> ProcrustesContext:
     """students: E tensors (B, N_s, D_s); teachers: L tensors (B, N_t, D_t); attns: L tensors (B, H, A, A);
     mix: (E, L) fp32 mixing weights on device.  Returns per-sample terms for every extraction layer."""
     E, L = len(students), len(teachers)
@@ -293,10 +294,11 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     tc = torch.empty((G, B, n, d_t), **f32)
     sb, sh, sq, sk = attns[0].stride()
     tsb, tsn, tsd = teachers[0].stride()
+    raw = torch.empty((G, B, n_a), **f32) if need_mix_grad else None
     for g in range(G):
         _lib.call("basd_token_weights", att_tab.data_ptr(), _dtype_code(attns[0]), mix[g].data_ptr(), L, sb, sh, sq,
                   sk, B, H, A, int(has_cls), n_a, n, n_s, a0, a1, alam, t0, t1, lam, omega[g].data_ptr(),
-                  omega_t[g].data_ptr(), None, st)
+                  omega_t[g].data_ptr(), raw[g].data_ptr() if need_mix_grad else None, st)
         _lib.call("basd_teacher_center", tok_tab.data_ptr(), _dtype_code(teachers[0]), mix[g].data_ptr(), L, tsb,
                   tsn, tsd, B, n, d_t, g0, g1, glam, omega_t[g].data_ptr(), mu_t[g].data_ptr(), tc[g].data_ptr(), st)
     mu_s = torch.empty((E, B, d_s), **f32)
@@ -334,12 +336,18 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     _lib.call("basd_procrustes_finalize", W.data_ptr(), 2 * n * n, sigma.data_ptr(), n, n_s, E * B, g_b.data_ptr(),
               n * n, omega_e.data_ptr(), t0, t1, lam, tr_part.data_ptr(), slabs, tr_s.data_ptr(), tr_t.data_ptr(),
               nuc.data_ptr(), loss_b.data_ptr(), _ptr(k_prime), st)
-    return ProcrustesContext(omega, mu_s, a_prime, k_prime, tr_s, tr_t, nuc, loss_b, sweeps)
+    mixgrad = None
+    if need_mix_grad:
+        mixgrad = dict(raw=raw, tc=tc, l_a=l_a, g_b=g_b, W=W, sigma=sigma, omega_e=omega_e, teachers=teachers,
+                       attns=attns, tok_tab=tok_tab, att_tab=att_tab, has_cls=has_cls, n_a=n_a, n=n, n_s=n_s,
+                       gather=gt, student_taps=tp, attn_taps=atp)
+    return ProcrustesContext(omega, mu_s, a_prime, k_prime, tr_s, tr_t, nuc, loss_b, sweeps, mixgrad)
 
 
-def procrustes_student_grads(students: list[torch.Tensor], ctx: ProcrustesContext,
-                             grad_layers: torch.Tensor) -> list[torch.Tensor]:
-    """d(sum_e grad_layers[e] * mean_b loss_b[e]) / d students[e]   (fp32, contiguous)."""
+def procrustes_student_grads(students: list[torch.Tensor], ctx: ProcrustesContext, grad_layers: torch.Tensor,
+                             tnorm2: torch.Tensor | None = None):
+    """d(sum_e grad_layers[e] * mean_b loss_b[e]) / d students[e]   (fp32, contiguous).
+    With ``tnorm2`` (E, B, n_s) also returns d loss_b / d omega (E, B, n_s), un-scaled."""
     E = len(students)
     _, B, n, d_s = ctx.a_prime.shape
     dev = ctx.a_prime.device
@@ -354,6 +362,7 @@ def procrustes_student_grads(students: list[torch.Tensor], ctx: ProcrustesContex
                 n_cols=d_s, split=False).view(E, B, n, d_s)
     grad_layers = grad_layers.contiguous().float()
     grads = []
+    gomega = torch.empty((E, B, n_s), device=dev, dtype=torch.float32) if tnorm2 is not None else None
     shared = ctx.omega.shape[0] == 1
     for e, x in enumerate(students):
         x = as_supported(x)
@@ -361,6 +370,87 @@ def procrustes_student_grads(students: list[torch.Tensor], ctx: ProcrustesContex
         dx = torch.empty((B, n_s, d_s), device=dev, dtype=torch.float32)
         _lib.call("basd_student_grad", x.data_ptr(), _dtype_code(x), x.stride(0), x.stride(1), B, n_s, n, d_s,
                   ctx.omega[0 if shared else e].data_ptr(), ctx.mu_s[e].data_ptr(), h[e].data_ptr(), t0, t1, lam,
-                  grad_layers[e:e + 1].data_ptr(), 2.0 / B, dx.data_ptr(), st)
+                  grad_layers[e:e + 1].data_ptr(), 2.0 / B, dx.data_ptr(),
+                  tnorm2[e].data_ptr() if tnorm2 is not None else None,
+                  gomega[e].data_ptr() if gomega is not None else None, st)
         grads.append(dx)
-    return grads
+    return (grads, gomega) if tnorm2 is not None else grads
+
+
+def procrustes_teacher_factor(ctx: ProcrustesContext) -> tuple[torch.Tensor, torch.Tensor]:
+    """(Kt (E*B, n, n), |t_hat_c|^2 (E, B, n_s)) -- see basd_teacher_factor."""
+    mg = ctx.mixgrad
+    E, B = ctx.loss_b.shape
+    n, n_s = mg["n"], mg["n_s"]
+    dev = ctx.loss_b.device
+    tp = mg["student_taps"]
+    t0, t1, lam = (tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr()) if tp else (None, None, None)
+    r0, r1 = (tp.range0.data_ptr(), tp.range1.data_ptr()) if tp else (None, None)
+    kt = torch.empty((E * B, n, n), device=dev, dtype=torch.float32)
+    tnorm2 = torch.empty((E, B, n_s), device=dev, dtype=torch.float32)
+    _lib.call("basd_teacher_factor", mg["W"].data_ptr(), 2 * n * n, mg["sigma"].data_ptr(), n, n_s, E * B,
+              mg["l_a"].data_ptr(), mg["g_b"].data_ptr(), n * n, mg["omega_e"].data_ptr(), t0, t1, lam, r0, r1,
+              kt.data_ptr(), tnorm2.data_ptr(), _stream())
+    return kt, tnorm2
+
+
+def procrustes_mix_grads(ctx: ProcrustesContext, kt: torch.Tensor, gomega: torch.Tensor,
+                         grad_layers: torch.Tensor) -> torch.Tensor:
+    """d(sum_e grad_layers[e] * mean_b loss_b[e]) / d mix  -> (E, L)."""
+    mg = ctx.mixgrad
+    E, B = ctx.loss_b.shape
+    n, n_s, n_a = mg["n"], mg["n_s"], mg["n_a"]
+    teachers, attns = mg["teachers"], mg["attns"]
+    L = len(teachers)
+    d_t = teachers[0].shape[2]
+    dev = ctx.loss_b.device
+    st = _stream()
+    tc = mg["tc"].view(E * B, n, d_t)
+    # R = Kt T_c per (layer, sample); Kt is symmetric, so the TN contraction applies
+    r = gemm_tn(kt[0], tc[0], batch=E * B, a_batch_stride=n * n, b_batch_stride=n * d_t, krows=n, m_cols=n,
+                n_cols=d_t, split=False)
+    gt = mg["gather"]
+    g0, g1, glam = (gt.tap0.data_ptr(), gt.tap1.data_ptr(), gt.lam.data_ptr()) if gt else (None, None, None)
+    part_tok = torch.empty((E, B, L), device=dev, dtype=torch.float32)
+    tsb, tsn, tsd = teachers[0].stride()
+    _lib.call("basd_mix_grad_tokens", r.data_ptr(), mg["tok_tab"].data_ptr(), _dtype_code(teachers[0]), L, tsb, tsn,
+              tsd, E, B, n, d_t, g0, g1, glam, part_tok.data_ptr(), st)
+    atp = mg["attn_taps"]
+    a0, a1, alam = (atp.tap0.data_ptr(), atp.tap1.data_ptr(), atp.lam.data_ptr()) if atp else (None, None, None)
+    ar0, ar1 = (atp.range0.data_ptr(), atp.range1.data_ptr()) if atp else (None, None)
+    sb, sh, sq, sk = attns[0].stride()
+    H, A = attns[0].shape[1], attns[0].shape[2]
+    part_att = torch.empty((E, B, L), device=dev, dtype=torch.float32)
+    _lib.call("basd_token_weight_bwd", gomega.data_ptr(), mg["raw"].data_ptr(), E, B, n_a, n_s, a0, a1, alam, ar0,
+              ar1, mg["att_tab"].data_ptr(), _dtype_code(attns[0]), L, sb, sh, sq, sk, H, A, int(mg["has_cls"]),
+              part_att.data_ptr(), st)
+    per_layer = (2.0 * part_tok + part_att).sum(dim=1) / B                 # (E, L): tiny torch glue
+    return per_layer * grad_layers.float().view(E, 1)
+
+
+# --------------------------------------------------------------------------- #
+# principal angles with a backward (multi-layer teachers)
+# --------------------------------------------------------------------------- #
+def angle_stack(cos: torch.Tensor, k_arr: torch.Tensor) -> torch.Tensor:
+    """(items, kmax, kmax) cosine matrices -> (items, kmax, 2 kmax) [masked cos ; I] stacks (column-major)."""
+    items, kmax, _ = cos.shape
+    out = torch.empty((items, kmax, 2 * kmax), device=cos.device, dtype=torch.float32)
+    _lib.call("basd_build_angle_stack", cos.data_ptr(), kmax, k_arr.data_ptr(), items, out.data_ptr(), _stream())
+    return out
+
+
+def grassmann_distance_bwd(stack: torch.Tensor, colnorm: torch.Tensor, k_arr: torch.Tensor, sw: torch.Tensor,
+                           sw_index: torch.Tensor, gd: torch.Tensor) -> torch.Tensor:
+    items, kmax, _ = stack.shape
+    gwt = torch.empty((items, kmax, kmax), device=stack.device, dtype=torch.float32)
+    _lib.call("basd_grassmann_distance_bwd", stack.data_ptr(), colnorm.data_ptr(), kmax, k_arr.data_ptr(),
+              sw.data_ptr(), sw.stride(0), sw_index.data_ptr(), gd.contiguous().data_ptr(), items, gwt.data_ptr(),
+              _stream())
+    return gwt
+
+
+def eigvec_k2(m: torch.Tensor, lam: torch.Tensor) -> torch.Tensor:
+    batch, D, kmax = m.shape
+    k2 = torch.empty((batch, D, D), device=m.device, dtype=torch.float32)
+    _lib.call("basd_eigvec_k2", m.data_ptr(), lam.data_ptr(), D, kmax, batch, k2.data_ptr(), _stream())
+    return k2

@@ -1,0 +1,372 @@
+// Backward pieces that only multi-layer (ViT) teachers need: the gradient of the loss with respect to the
+// soft layer-mixing weights (reference layer_selector.py:107-112 feeding relational.py) and, through the
+// principal angles, with respect to the student tokens ("route (b)" of SURVEY.md section 3.2: autograd of
+// layer_selector.py:86-105, i.e. svdvals -> acos -> weighted distance -> eigenvector perturbation of the
+// student Gram).  With a single teacher layer these gradients are exactly zero and none of this runs.
+#include "basd_common.h"
+
+namespace basd {
+
+// ---------------------------------------------------------------------------
+// Teacher-side factor of the Procrustes gradient.  d loss_b / d T_c = 2 (Q - K'') T_c  with
+//   Q   = I^T diag(w) I                       (trace term, on the core grid)
+//   K'' = Z Sigma^+ Z^T,  Z = L_a U           (nuclear-norm term; U Sigma = rotated top half of W)
+// grid = batch, block = 256.  Also emits |t_hat_c[s]|^2 per student token (for d loss / d omega).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) teacher_factor_kernel(
+    const float* __restrict__ W, long w_batch_stride, const float* __restrict__ sigma, int n, int n_s,
+    const double* __restrict__ La, const double* __restrict__ Gb, long g_batch_stride,
+    const float* __restrict__ omega, const int* __restrict__ tap0, const int* __restrict__ tap1,
+    const float* __restrict__ lam, const int* __restrict__ range0, const int* __restrict__ range1,
+    float* __restrict__ Kt, float* __restrict__ tnorm2) {
+    extern __shared__ float sm[];
+    float* s15 = sm;          // n : sigma^-1.5 or 0
+    float* Zs = sm + n;       // n*n, column-major: Zs[c*n + a] = z_c[a] * sigma_c^-1/2
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* sg = sigma + (long)b * n;
+    float smax = 0.f;
+    for (int j = tid; j < n; j += 256) smax = fmaxf(smax, sg[j]);
+    smax = wave_max(smax);
+    if ((tid & 63) == 0) red[tid >> 6] = smax;
+    __syncthreads();
+    smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float thr = smax * (float)n * 1.1920929e-7f;
+    for (int j = tid; j < n; j += 256) {
+        const float s = sg[j];
+        s15[j] = s > thr ? 1.f / (s * sqrtf(s)) : 0.f;
+    }
+    __syncthreads();
+    const float* Wb = W + (long)b * w_batch_stride;
+    const double* L = La + (long)b * g_batch_stride;
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int c = idx / n, a = idx - c * n;
+        const float* col = Wb + (long)c * 2 * n;
+        float acc = 0.f;
+        for (int r = 0; r <= a; ++r) acc = fmaf((float)L[(long)a * n + r], col[r], acc);
+        Zs[idx] = acc * s15[c];
+    }
+    __syncthreads();
+    const float* w = omega + (long)b * n_s;
+    float* K = Kt + (long)b * n * n;
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int a = idx / n, bb = idx - a * n;
+        float q = 0.f;
+        if (tap0) {
+            const int s0 = max(range0[a], range0[bb]), s1 = min(range1[a], range1[bb]);
+            for (int s = s0; s < s1; ++s) {
+                const float l1 = lam[s];
+                const float ca = (tap0[s] == a ? 1.f - l1 : 0.f) + (tap1[s] == a ? l1 : 0.f);
+                const float cb = (tap0[s] == bb ? 1.f - l1 : 0.f) + (tap1[s] == bb ? l1 : 0.f);
+                q = fmaf(w[s] * ca, cb, q);
+            }
+        } else if (a == bb) {
+            q = w[a];
+        }
+        float acc = 0.f;
+        for (int c = 0; c < n; ++c) acc = fmaf(Zs[c * n + a], Zs[c * n + bb], acc);
+        K[idx] = q - acc;
+    }
+    const double* G = Gb + (long)b * g_batch_stride;
+    for (int s = tid; s < n_s; s += 256) {
+        double v;
+        if (tap0) {
+            const int i0 = tap0[s], i1 = tap1[s];
+            const double l1 = (double)lam[s], l0 = 1. - l1;
+            v = l0 * l0 * G[(long)i0 * n + i0] + 2. * l0 * l1 * G[(long)i0 * n + i1] + l1 * l1 * G[(long)i1 * n + i1];
+        } else {
+            v = G[(long)s * n + s];
+        }
+        tnorm2[(long)b * n_s + s] = (float)v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// partial[e][b][l] = < R[e][b] , That_l[b] >   (R = (Q - K'') T_c on the core grid of n tokens;
+// That_l = teacher layer l on that grid: gathered with (g0, g1, glam) when the teacher grid is finer).
+// grid = (L, B, E), block = 256.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) mix_grad_tokens_kernel(const float* __restrict__ R,
+                                                              const void* const* __restrict__ tok_ptrs, long sb,
+                                                              long sn, long sd, int n, int D,
+                                                              const int* __restrict__ g0, const int* __restrict__ g1,
+                                                              const float* __restrict__ glam,
+                                                              float* __restrict__ partial) {
+    __shared__ float red[32];
+    const int l = blockIdx.x, b = blockIdx.y, e = blockIdx.z, B = gridDim.y, L = gridDim.x;
+    const float* r = R + ((long)e * B + b) * n * D;
+    const T* t = (const T*)tok_ptrs[l] + (long)b * sb;
+    float acc = 0.f;
+    for (int idx = threadIdx.x; idx < n * D; idx += 256) {
+        const int j = idx / D, d = idx - j * D;
+        float tv;
+        if (g0) {
+            const float l1 = glam[j];
+            tv = (1.f - l1) * to_f32(t[(long)g0[j] * sn + (long)d * sd]) + l1 * to_f32(t[(long)g1[j] * sn + (long)d * sd]);
+        } else {
+            tv = to_f32(t[(long)j * sn + (long)d * sd]);
+        }
+        acc = fmaf(r[idx], tv, acc);
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[((long)e * B + b) * L + l] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// Chain d loss / d omega back to the mixing weights through relational.py:22-34 and layer_selector.py:112:
+// normalisation, weight interpolation (n_a -> n_s), head / query mean, layer mix.
+// partial[e][b][l] = sum_j g_raw[j] * rowmean_l[b][j].     grid = (B, E), block = 256.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) token_weight_bwd_kernel(
+    const float* __restrict__ gomega, const float* __restrict__ raw, int n_a, int n_s,
+    const int* __restrict__ atap0, const int* __restrict__ atap1, const float* __restrict__ alam,
+    const int* __restrict__ arange0, const int* __restrict__ arange1, const void* const* __restrict__ attn_ptrs,
+    int L, long sb, long sh, long sq, long sk, int H, int A, int has_cls, float* __restrict__ partial) {
+    extern __shared__ float sm[];
+    float* gv = sm;             // n_s
+    float* graw = sm + n_s;     // n_a
+    __shared__ float red[32];
+    const int b = blockIdx.x, e = blockIdx.y, B = gridDim.x, tid = threadIdx.x;
+    const float* rw = raw + ((long)e * B + b) * n_a;
+    const float* go = gomega + ((long)e * B + b) * n_s;
+    float tot = 0.f;
+    for (int s = tid; s < n_s; s += 256) {
+        float v;
+        if (atap0) {
+            const float l1 = alam[s];
+            v = (1.f - l1) * rw[atap0[s]] + l1 * rw[atap1[s]];
+        } else {
+            v = rw[s];
+        }
+        gv[s] = v;
+        tot += v;
+    }
+    const float total = block_sum(tot, red);
+    float dotp = 0.f;
+    for (int s = tid; s < n_s; s += 256) dotp = fmaf(go[s], gv[s] / total, dotp);
+    const float c = block_sum(dotp, red);
+    for (int s = tid; s < n_s; s += 256) gv[s] = (go[s] - c) / total;      // d / d (interpolated raw weight)
+    __syncthreads();
+    for (int j = tid; j < n_a; j += 256) {
+        float acc = 0.f;
+        if (atap0) {
+            for (int s = arange0[j]; s < arange1[j]; ++s) {
+                const float l1 = alam[s];
+                acc = fmaf((atap0[s] == j ? 1.f - l1 : 0.f) + (atap1[s] == j ? l1 : 0.f), gv[s], acc);
+            }
+        } else {
+            acc = gv[j];
+        }
+        graw[j] = acc;
+    }
+    __syncthreads();
+    for (int l = 0; l < L; ++l) {
+        const T* a = (const T*)attn_ptrs[l] + (long)b * sb;
+        float acc = 0.f;
+        for (int j = tid; j < n_a; j += 256) {
+            float m = 0.f;
+            if (has_cls) {
+                for (int h = 0; h < H; ++h) m += to_f32(a[h * sh + (long)(1 + j) * sk]);
+                m /= (float)H;
+            } else {
+                for (int h = 0; h < H; ++h)
+                    for (int q = 0; q < A; ++q) m += to_f32(a[h * sh + q * sq + (long)j * sk]);
+                m /= (float)(H * A);
+            }
+            acc = fmaf(graw[j], m, acc);
+        }
+        acc = block_sum(acc, red);
+        if (tid == 0) partial[((long)e * B + b) * L + l] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stack the (masked) cosine matrix on top of an identity so that the Jacobi solver accumulates the right
+// singular vectors:  out[item] is column-major (2 kmax x kmax): column c = [cos[item][c][0..k) , 0.. ; e_c].
+// grid = items, block = 256.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) build_angle_stack_kernel(const float* __restrict__ cos, int kmax,
+                                                                const int* __restrict__ k_arr,
+                                                                float* __restrict__ out) {
+    const int m = blockIdx.x, k = k_arr[m];
+    const float* cm = cos + (long)m * kmax * kmax;
+    float* o = out + (long)m * 2 * kmax * kmax;
+    for (int idx = threadIdx.x; idx < 2 * kmax * kmax; idx += 256) {
+        const int c = idx / (2 * kmax), r = idx - c * 2 * kmax;
+        float v;
+        if (r < kmax) v = (c < k && r < k) ? cm[(long)c * kmax + r] : 0.f;
+        else v = (r - kmax == c) ? 1.f : 0.f;
+        o[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// d (d_grass_sq) / d W for one (student layer, teacher layer) item, W = Vt_s[:k] U_t  (k x k):
+//   W = V_A Sigma U_A^T  (the solver saw A = W^T),   dd/dW = V_A diag(f') U_A^T,
+//   f'_p = g * sw_p * (-2 theta_p / sqrt(1 - s_p^2)) / sum(sw)   for s_p < 1 - eps, else 0 (the clamp).
+// Emits gWt[item][j][i] = dd/dW[i][j] (kmax x kmax, zero outside k x k).   grid = items, block = 256.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) grassmann_distance_bwd_kernel(
+    const float* __restrict__ stack, const float* __restrict__ colnorm, int kmax, const int* __restrict__ k_arr,
+    const float* __restrict__ sw, int sw_stride, const int* __restrict__ sw_index, const float* __restrict__ gd,
+    float* __restrict__ gWt) {
+    __shared__ float key[1024];
+    __shared__ int idx[1024];
+    __shared__ float coef[1024];
+    __shared__ float red[32];
+    const int m = blockIdx.x, tid = threadIdx.x, k = k_arr[m];
+    int np2 = 1;
+    while (np2 < kmax) np2 <<= 1;
+    for (int i = tid; i < np2; i += 256) {
+        key[i] = i < kmax ? colnorm[(long)m * kmax + i] : -1.f;
+        idx[i] = i;
+        coef[i] = 0.f;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= np2; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool desc = (i & kk) == 0;
+                    const float a = key[i], b = key[l];
+                    const bool a_first = a > b || (a == b && idx[i] < idx[l]);
+                    if (desc ? !a_first : a_first) {
+                        key[i] = b; key[l] = a;
+                        const int t = idx[i]; idx[i] = idx[l]; idx[l] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const float* w = sw + (long)sw_index[m] * sw_stride;
+    float den = 0.f;
+    for (int i = tid; i < k; i += 256) den += w[i];
+    den = block_sum(den, red);
+    const float g = gd[m];
+    for (int p = tid; p < k; p += 256) {
+        const float s = key[p];
+        const float lim = 1.f - 1.1920929e-7f;
+        float f = 0.f;
+        if (s < lim && s > 1e-20f) {
+            const float th = acosf(s);
+            f = g * w[p] * (-2.f * th / sqrtf(1.f - s * s)) / den;
+            f /= s;                       // U_A column = rotated top column / sigma
+        }
+        coef[idx[p]] = f;
+    }
+    __syncthreads();
+    const float* st = stack + (long)m * 2 * kmax * kmax;
+    float* out = gWt + (long)m * kmax * kmax;
+    for (int e = tid; e < kmax * kmax; e += 256) {
+        const int j = e / kmax, i = e - j * kmax;
+        float acc = 0.f;
+        if (i < k && j < k)
+            for (int c = 0; c < kmax; ++c) {
+                const float* col = st + (long)c * 2 * kmax;
+                acc = fmaf(coef[c] * col[j], col[kmax + i], acc);
+            }
+        out[e] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Eigenvector-perturbation kernel of a symmetric matrix S = V diag(lam) V^T (lam descending):
+// for a loss with d/dV = G (only the first kmax columns non-zero) and M = V^T G (D x kmax),
+//   d/dS + (d/dS)^T = V K2 V^T,   K2[i][j] = (M[i][j] - M[j][i]) / (lam_j - lam_i),  K2[i][i] = 0.
+// grid = (ceil(D*D/256), batch), block = 256.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) eigvec_k2_kernel(const float* __restrict__ M, const float* __restrict__ lam,
+                                                        int D, int kmax, float* __restrict__ K2) {
+    const int z = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= D * D) return;
+    const int i = e / D, j = e - i * D;
+    const float* Mz = M + (long)z * D * kmax;
+    const float* lz = lam + (long)z * D;
+    float v = 0.f;
+    if (i != j && (i < kmax || j < kmax)) {
+        const float mij = j < kmax ? Mz[(long)i * kmax + j] : 0.f;
+        const float mji = i < kmax ? Mz[(long)j * kmax + i] : 0.f;
+        const float den = lz[j] - lz[i];
+        if (fabsf(den) > 1e-6f * lz[0]) v = (mij - mji) / den;
+    }
+    K2[(long)z * D * D + e] = v;
+}
+
+}  // namespace basd
+
+using namespace basd;
+
+extern "C" {
+
+// Kt = Q - K'' (teacher-side gradient factor, see kernel) and |t_hat_c|^2 per student token.
+int basd_teacher_factor(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
+                        const double* la, const double* gb, long g_batch_stride, const float* omega,
+                        const int* tap0, const int* tap1, const float* lam, const int* range0, const int* range1,
+                        float* kt, float* tnorm2, hipStream_t stream) {
+    BASD_CHECK_ARG(w && sigma && la && gb && omega && kt && tnorm2 && n > 0 && n_s > 0 && batch > 0);
+    const size_t lds = sizeof(float) * ((size_t)n + (size_t)n * n);
+    if (lds > 156 * 1024) return BASD_EUNSUPPORTED;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)teacher_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    teacher_factor_kernel<<<batch, 256, lds, stream>>>(w, w_batch_stride, sigma, n, n_s, la, gb, g_batch_stride, omega,
+                                                       tap0, tap1, lam, range0, range1, kt, tnorm2);
+    BASD_RETURN_LAST();
+}
+
+// partial[e][b][l] = <R[e][b], teacher layer l on the core grid>.   R: (E, B, n, D) fp32.
+int basd_mix_grad_tokens(const float* r, const void* const* tok_ptrs, int dtype, int L, long sb, long sn, long sd,
+                         int E, int B, int n, int D, const int* g0, const int* g1, const float* glam, float* partial,
+                         hipStream_t stream) {
+    BASD_CHECK_ARG(r && tok_ptrs && partial && L > 0 && E > 0 && B > 0 && n > 0 && D > 0);
+    const dim3 grid(L, B, E);
+    if (dtype == BASD_DTYPE_F32)
+        mix_grad_tokens_kernel<float><<<grid, 256, 0, stream>>>(r, tok_ptrs, sb, sn, sd, n, D, g0, g1, glam, partial);
+    else if (dtype == BASD_DTYPE_BF16)
+        mix_grad_tokens_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(r, tok_ptrs, sb, sn, sd, n, D, g0, g1, glam, partial);
+    else
+        return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+// partial[e][b][l] = d loss / d mix_l through the token weights.  gomega: (E, B, n_s); raw: (E, B, n_a).
+int basd_token_weight_bwd(const float* gomega, const float* raw, int E, int B, int n_a, int n_s, const int* atap0,
+                          const int* atap1, const float* alam, const int* arange0, const int* arange1,
+                          const void* const* attn_ptrs, int dtype, int L, long sb, long sh, long sq, long sk, int H,
+                          int A, int has_cls, float* partial, hipStream_t stream) {
+    BASD_CHECK_ARG(gomega && raw && attn_ptrs && partial && E > 0 && B > 0 && n_a > 0 && n_s > 0 && L > 0);
+    BASD_CHECK_ARG((n_a == n_s) == (atap0 == nullptr));
+    const size_t lds = sizeof(float) * (size_t)(n_s + n_a);
+    const dim3 grid(B, E);
+    if (dtype == BASD_DTYPE_F32)
+        token_weight_bwd_kernel<float><<<grid, 256, lds, stream>>>(gomega, raw, n_a, n_s, atap0, atap1, alam, arange0, arange1, attn_ptrs, L, sb, sh, sq, sk, H, A, has_cls, partial);
+    else if (dtype == BASD_DTYPE_BF16)
+        token_weight_bwd_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>(gomega, raw, n_a, n_s, atap0, atap1, alam, arange0, arange1, attn_ptrs, L, sb, sh, sq, sk, H, A, has_cls, partial);
+    else
+        return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+int basd_build_angle_stack(const float* cos, int kmax, const int* k_arr, int items, float* out, hipStream_t stream) {
+    BASD_CHECK_ARG(cos && k_arr && out && kmax > 0 && items > 0);
+    build_angle_stack_kernel<<<items, 256, 0, stream>>>(cos, kmax, k_arr, out);
+    BASD_RETURN_LAST();
+}
+
+int basd_grassmann_distance_bwd(const float* stack, const float* colnorm, int kmax, const int* k_arr, const float* sw,
+                                int sw_stride, const int* sw_index, const float* gd, int items, float* gwt,
+                                hipStream_t stream) {
+    BASD_CHECK_ARG(stack && colnorm && k_arr && sw && sw_index && gd && gwt && kmax > 0 && kmax <= 1024 && items > 0);
+    grassmann_distance_bwd_kernel<<<items, 256, 0, stream>>>(stack, colnorm, kmax, k_arr, sw, sw_stride, sw_index, gd, gwt);
+    BASD_RETURN_LAST();
+}
+
+int basd_eigvec_k2(const float* m, const float* lam, int D, int kmax, int batch, float* k2, hipStream_t stream) {
+    BASD_CHECK_ARG(m && lam && k2 && D > 0 && kmax > 0 && kmax <= D && batch > 0);
+    eigvec_k2_kernel<<<dim3((D * D + 255) / 256, batch), 256, 0, stream>>>(m, lam, D, kmax, k2);
+    BASD_RETURN_LAST();
+}
+
+}  // extern "C"

@@ -39,7 +39,8 @@ __device__ __forceinline__ long row_off(const GemmOperand& o, long m) {
 }
 
 __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int M, int N, int m0, int n0,
-                                           const f32x16 (&acc)[2][2], int wm, int wn, int lane, float scale) {
+                                           const f32x16 (&acc)[2][2], int wm, int wn, int lane, float scale,
+                                           const float* __restrict__ bias = nullptr, float beta = 0.f) {
     const int col_l = lane & 31, hi = lane >> 5;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -47,10 +48,15 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int 
         for (int ni = 0; ni < 2; ++ni) {
             const int col = n0 + wn * 64 + ni * 32 + col_l;
             if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row < M) C[(long)row * ldc + col] = acc[mi][ni][r] * scale;
+                if (row < M) {
+                    float v = acc[mi][ni][r] * scale - bv;
+                    if (beta != 0.f) v = fmaf(beta, C[(long)row * ldc + col], v);
+                    C[(long)row * ldc + col] = v;
+                }
             }
         }
 }
@@ -120,7 +126,7 @@ __device__ __forceinline__ void nt_store_lds(float* __restrict__ tile, int tid, 
 template <typename TA, bool VEC_A>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand B, int M, int N, int K,
                                                       float* __restrict__ C, long ldc, long c_batch_stride,
-                                                      float scale) {
+                                                      float scale, const float* __restrict__ bias, float beta) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 128 * NT_LD];
     float* tA = lds;
     float* tB = lds + 128 * NT_LD;
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand
                 }
         }
     }
-    store_tile(C, ldc, M, N, m0, n0, acc, wm, wn, lane, scale);
+    store_tile(C, ldc, M, N, m0, n0, acc, wm, wn, lane, scale, bias, beta);
 }
 
 // ---------------------------------------------------------------------------
@@ -353,12 +359,13 @@ static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" {
 
-// C[z] (M x N, ldc) = scale * A[z] (M x K) * B[z]^T (N x K).
+// C[z] (M x N, ldc) = beta * C[z] + scale * A[z] (M x K) * B[z]^T (N x K) - 1 bias^T.
 //   A: element (m, k) at a + z*a_batch_stride + (m / a_rows_per_batch)*a_sb + (m % a_rows_per_batch)*a_sn + k*a_sd,
-//      dtype fp32 or bf16.   B: fp32, row-major with leading dimension ldb.
+//      dtype fp32 or bf16.   B: fp32, row-major with leading dimension ldb.  bias (nullable): N floats.
 int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, int a_rows_per_batch,
                  long a_batch_stride, const float* b, long ldb, long b_batch_stride, int M, int N, int K, int batch,
-                 float* c, long ldc, long c_batch_stride, float scale, hipStream_t stream) {
+                 float* c, long ldc, long c_batch_stride, float scale, const float* bias, float beta,
+                 hipStream_t stream) {
     BASD_CHECK_ARG(a && b && c && M > 0 && N > 0 && K > 0 && batch > 0 && a_rows_per_batch > 0);
     BASD_CHECK_ARG(aligned16(b) && ldb % 4 == 0 && b_batch_stride % 4 == 0);
     GemmOperand A{a, a_sb, a_sn, a_sd, a_rows_per_batch, a_batch_stride};
@@ -366,11 +373,11 @@ int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, in
     const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     if (a_dtype == BASD_DTYPE_F32) {
         const bool vec = a_sd == 1 && aligned16(a) && a_sb % 4 == 0 && a_sn % 4 == 0 && a_batch_stride % 4 == 0;
-        if (vec) gemm_nt_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale);
-        else gemm_nt_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale);
+        if (vec) gemm_nt_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta);
+        else gemm_nt_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta);
     } else if (a_dtype == BASD_DTYPE_BF16) {
-        if (a_sd == 1) gemm_nt_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale);
-        else gemm_nt_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale);
+        if (a_sd == 1) gemm_nt_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta);
+        else gemm_nt_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta);
     } else {
         return BASD_EINVAL;
     }

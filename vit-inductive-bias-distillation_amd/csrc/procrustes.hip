@@ -475,6 +475,8 @@ __global__ void __launch_bounds__(256) procrustes_finalize_kernel(
 // ---------------------------------------------------------------------------
 // Backward, student tokens:  dX[b,s,:] = coef * w_s * ( (x_s - mu) - interp(H)[s] ),
 //   H = K' A' (n_t x D),  coef = *scale_ptr * scale_const.     grid = (n_s, B), block = 128
+// Optionally also d loss_b / d omega_s = |x_c|^2 + |t_hat_c|^2 - 2 x_c . interp(H)_s  (un-scaled),
+// needed only when the mixing weights carry a gradient (multi-layer teachers).
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(128) student_grad_kernel(const T* __restrict__ X, long sb, long sn, int n_s, int n_t,
@@ -483,7 +485,9 @@ __global__ void __launch_bounds__(128) student_grad_kernel(const T* __restrict__
                                                            const int* __restrict__ tap0, const int* __restrict__ tap1,
                                                            const float* __restrict__ lam,
                                                            const float* __restrict__ scale_ptr, float scale_const,
-                                                           float* __restrict__ dX) {
+                                                           float* __restrict__ dX, const float* __restrict__ tnorm2,
+                                                           float* __restrict__ gomega) {
+    __shared__ float red[32];
     const int s = blockIdx.x, b = blockIdx.y;
     const float coef = scale_ptr[0] * scale_const * omega[(long)b * n_s + s];
     const T* x = X + (long)b * sb + (long)s * sn;
@@ -498,12 +502,20 @@ __global__ void __launch_bounds__(128) student_grad_kernel(const T* __restrict__
     const float* h0 = H + ((long)b * n_t + i0) * D;
     const float* h1 = H + ((long)b * n_t + i1) * D;
     float* out = dX + ((long)b * n_s + s) * D;
+    float xx = 0.f, xt = 0.f;
     for (int d = threadIdx.x; d < D; d += 128) {
         const float tgt = (1.f - l1) * h0[d] + l1 * h1[d];
-        out[d] = coef * ((to_f32(x[d]) - m[d]) - tgt);
+        const float xc = to_f32(x[d]) - m[d];
+        out[d] = coef * (xc - tgt);
+        xx = fmaf(xc, xc, xx);
+        xt = fmaf(xc, tgt, xt);
+    }
+    if (gomega) {
+        xx = block_sum(xx, red);
+        xt = block_sum(xt, red);
+        if (threadIdx.x == 0) gomega[(long)b * n_s + s] = xx + tnorm2[(long)b * n_s + s] - 2.f * xt;
     }
 }
-
 
 // ---------------------------------------------------------------------------
 // Stand-alone token-count interpolation (reference combined.py:9-14), used by the public
@@ -660,13 +672,15 @@ int basd_procrustes_finalize(const float* w, long w_batch_stride, const float* s
 // Gradient of sum_b coef * loss_b with respect to the student tokens (autograd of relational.py:36-50).
 int basd_student_grad(const void* x, int dtype, long sb, long sn, int B, int n_s, int n_t, int D, const float* omega,
                       const float* mu, const float* h, const int* tap0, const int* tap1, const float* lam,
-                      const float* scale_ptr, float scale_const, float* dx, hipStream_t stream) {
+                      const float* scale_ptr, float scale_const, float* dx, const float* tnorm2, float* gomega,
+                      hipStream_t stream) {
     BASD_CHECK_ARG(x && omega && mu && h && scale_ptr && dx && B > 0 && n_s > 0 && n_t > 0 && D > 0);
+    BASD_CHECK_ARG((gomega == nullptr) || (tnorm2 != nullptr));
     const dim3 grid(n_s, B);
     if (dtype == BASD_DTYPE_F32)
-        student_grad_kernel<float><<<grid, 128, 0, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx);
+        student_grad_kernel<float><<<grid, 128, 0, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx, tnorm2, gomega);
     else if (dtype == BASD_DTYPE_BF16)
-        student_grad_kernel<__hip_bfloat16><<<grid, 128, 0, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx);
+        student_grad_kernel<__hip_bfloat16><<<grid, 128, 0, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx, tnorm2, gomega);
     else
         return BASD_EINVAL;
     BASD_RETURN_LAST();
