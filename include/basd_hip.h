@@ -85,6 +85,24 @@ int basd_sort_extract(const float* W, long batch_stride, int rows, int rows_tot,
                       const float* colnorm, int colnorm_stride, float* vals_desc, float* vecs, int kmax,
                       hipStream_t stream);
 
+/* ---- tridiagonalisation-based symmetric eigen-solver (eigenvalues / leading eigenvectors only) ------- */
+
+/* Householder tridiagonalisation A = Q T Q^T of `batch` symmetric n x n matrices (A destroyed):
+ * first stage of the LAPACK path behind torch.linalg.eigvalsh (layer_selector.py:16) and the
+ * Vt[:k] / S[:k] part of torch.linalg.svd (:36, :92).  d, e, tau: (batch, n); vh: (batch, n, n). */
+int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
+                 hipStream_t stream);
+
+/* All eigenvalues (descending) of the tridiagonals by Sturm-sequence bisection. */
+int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, float* vals_desc, hipStream_t stream);
+
+/* Leading k eigenvectors of the original matrices (inverse iteration on T, cluster re-orthogonalisation,
+ * back-transformation with the reflectors), written as rows of vecs (batch, k_stride, n).
+ * z: batch*k*n floats of scratch. */
+int basd_tridiag_eigenvectors(const float* d, const float* e, const float* tau, const float* vh,
+                              const float* vals_desc, int n, int k, int batch, float* z, float* vecs, int k_stride,
+                              hipStream_t stream);
+
 /* ---- selector epilogues --------------------------------------------------------------------- */
 
 /* rank = min(#{eig > fp32(median_lower(eig) * factor)}, cap).  layer_selector.py:17-19, :74.

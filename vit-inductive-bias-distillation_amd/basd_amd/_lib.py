@@ -26,6 +26,9 @@ SIGNATURES = {
     "basd_jacobi_workspace_ints": [i32, i32],
     "basd_jacobi_onesided": [vp, i64, i32, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp],
     "basd_sort_extract": [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
+    "basd_tridiag": [vp, i64, i32, i32, vp, vp, vp, vp, vp],
+    "basd_tridiag_eigenvalues": [vp, vp, i32, i32, vp, vp],
+    "basd_tridiag_eigenvectors": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp],
     "basd_mp_rank": [vp, i32, i32, f64, i32, vp, vp, vp],
     "basd_grassmann_distance": [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp],
     "basd_sqrt_clamp": [vp, vp, i64, vp],

@@ -35,12 +35,19 @@ def _uncentred_gram(features: torch.Tensor) -> torch.Tensor:
     return ops.gemm_nt(x, x, scale=1.0 / M)
 
 
+def _eigenvalues_desc(grams: torch.Tensor) -> torch.Tensor:
+    """All eigenvalues (descending) of a batch of symmetric matrices (destroyed)."""
+    if ops.EIG_SOLVER == "tridiag" and grams.shape[1] >= 2:
+        return ops.tridiag_eigenvalues(grams).vals
+    return ops.sym_eig(grams)[0]
+
+
 @torch.no_grad()
 def marchenko_pastur_rank(features: torch.Tensor) -> int:
     features = ops.as_supported(features)
     M, D = features.shape
-    gram = _uncentred_gram(features).unsqueeze(0)
-    vals, _, _, _ = ops.sym_eig(gram)
+    gram = _uncentred_gram(features).unsqueeze(0).contiguous()
+    vals = _eigenvalues_desc(gram)
     rank = ops.mp_rank_device(vals, M, D, cap=1 << 30)
     return int(rank.item())
 
@@ -145,7 +152,7 @@ class _GrassmannDistance(torch.autograd.Function):
     @staticmethod
     def forward(ctx, selector, keys, teachers, *students):
         want_grad = any(s.requires_grad for s in students)
-        spectra = selector._spectra_async(list(students), teachers)
+        spectra = selector._spectra_async(list(students), teachers, all_student_vectors=want_grad)
         d, saved = selector._angles_from_spectra(spectra, keys, want_grad=want_grad)
         ctx.saved = saved
         ctx.selector = selector
@@ -233,24 +240,32 @@ class GrassmannianLayerSelector(nn.Module):
         teachers = ops._check_common_layout([ops.as_supported(all_teacher_tokens[k]) for k in keys],
                                             "teacher token tensors")
         g_u, _, M = self._teacher_grams(teachers)
-        vals_u, _, _, _ = ops.sym_eig(g_u)
+        vals_u = _eigenvalues_desc(g_u)
         ranks_dev = ops.mp_rank_device(vals_u, M, self.student_dim, cap=self.student_dim - 1)   # :74
         for k, r in zip(keys, ranks_dev.tolist()):
             self.subspace_ranks[k] = int(r)
 
     # ---- distances + mixing weights ------------------------------------------------------
     @torch.no_grad()
-    def _spectra_async(self, students: list[torch.Tensor], teachers: list[torch.Tensor]) -> dict:
+    def _spectra_async(self, students: list[torch.Tensor], teachers: list[torch.Tensor],
+                       all_student_vectors: bool = False) -> dict:
         """Queue every Gram matrix and eigen-solve of the step on the current stream; no host sync.
-        (layer_selector.py:69-74, :131-138, :86-92)"""
+        (layer_selector.py:69-74, :131-138, :86-92)
+
+        Solver choice: the teacher matrices need eigenvalues (MP rank) and the leading k eigenvectors, the
+        student matrices the leading k eigenvectors -- tridiagonalisation + bisection + inverse iteration.
+        Only the backward of multi-layer teachers needs ALL student eigenvectors: those go through Jacobi."""
         d_s = self.student_dim
         E, L = len(students), len(teachers)
         dev = students[0].device
         g_u, g_c, M = self._teacher_grams(teachers)
         same = g_u.shape[1] == d_s
-        # every symmetric eigen-problem of the step goes through ONE solver call:
-        # [teacher uncentred (L) | teacher centred (L) | student centred (E)]
-        stack = torch.empty(((2 * L if same else L) + E, d_s, d_s), device=dev, dtype=torch.float32)
+        tri = ops.EIG_SOLVER == "tridiag"
+        stud_jacobi = all_student_vectors or not tri
+        # one batched solver call per solver: [teacher uncentred (L) | teacher centred (L) | student centred (E)]
+        n_main = (2 * L if same else L) + (0 if (tri and stud_jacobi) else E)
+        stack = torch.empty((n_main, d_s, d_s), device=dev, dtype=torch.float32)
+        s_stack = torch.empty((E, d_s, d_s), device=dev, dtype=torch.float32) if (tri and stud_jacobi) else None
         o_c = L if same else 0
         if same:
             stack[:L] = g_u
@@ -262,14 +277,27 @@ class GrassmannianLayerSelector(nn.Module):
             means.append(mean)
             # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
             # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
-            stack[o_c + L + e] = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
-        colnorm = ops.jacobi_onesided(stack, d_s)
-        if same:
-            vals_u, _ = ops.sort_extract(stack[:L], colnorm[:L], 0)
+            gram = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
+            if s_stack is not None:
+                s_stack[e] = gram
+            else:
+                stack[o_c + L + e] = gram
+        st = dict(o_c=o_c, E=E, L=L, means=means, tri=tri, stud_jacobi=stud_jacobi)
+        if tri:
+            ts = ops.tridiag_eigenvalues(stack)
+            st["ts"] = ts
+            vals_u = ts.vals[:L] if same else ops.tridiag_eigenvalues(g_u).vals
+            if s_stack is not None:
+                st["s_stack"], st["s_colnorm"] = s_stack, ops.jacobi_onesided(s_stack, d_s)
         else:
-            vals_u, _, _, _ = ops.sym_eig(g_u)
-        ranks_dev = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
-        return dict(stack=stack, colnorm=colnorm, ranks_dev=ranks_dev, o_c=o_c, E=E, L=L, means=means)
+            colnorm = ops.jacobi_onesided(stack, d_s)
+            st["stack"], st["colnorm"] = stack, colnorm
+            if same:
+                vals_u, _ = ops.sort_extract(stack[:L], colnorm[:L], 0)
+            else:
+                vals_u, _, _, _ = ops.sym_eig(g_u)
+        st["ranks_dev"] = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
+        return st
 
     @torch.no_grad()
     def _angles_from_spectra(self, st: dict, keys: list[int], want_grad: bool = False):
@@ -277,8 +305,8 @@ class GrassmannianLayerSelector(nn.Module):
         (layer_selector.py:95-105).  Refreshes ``subspace_ranks``.  Returns (d, saved state for
         ``_distance_backward`` or None)."""
         d_s = self.student_dim
-        stack, colnorm, ranks_dev, o_c, E, L = (st[k] for k in ("stack", "colnorm", "ranks_dev", "o_c", "E", "L"))
-        dev = stack.device
+        ranks_dev, o_c, E, L = (st[k] for k in ("ranks_dev", "o_c", "E", "L"))
+        dev = ranks_dev.device
         ranks = [int(r) for r in ranks_dev.tolist()]
         for k, r in zip(keys, ranks):
             self.subspace_ranks[k] = r
@@ -288,10 +316,23 @@ class GrassmannianLayerSelector(nn.Module):
                 "linalg.svd: The algorithm failed to converge because the input matrix contained "
                 "non-finite values (a teacher layer has Marchenko-Pastur rank 0).")
         kmax = max(ranks)
-        vals_c, u_t = ops.sort_extract(stack[o_c:o_c + L], colnorm[o_c:o_c + L], kmax)   # (L, kmax, d_s)
+        n_stud = d_s if want_grad else kmax
+        if st["tri"]:
+            ts = st["ts"]
+            vals_c = ts.vals[o_c:o_c + L]
+            u_t = ops.tridiag_eigenvectors(ts, kmax, first=o_c, count=L)                 # (L, kmax, d_s)
+            if st["stud_jacobi"]:
+                lam_s, v_all = ops.sort_extract(st["s_stack"], st["s_colnorm"], n_stud)
+            else:
+                assert not want_grad
+                lam_s = ts.vals[o_c + L:]
+                v_all = ops.tridiag_eigenvectors(ts, kmax, first=o_c + L, count=E)
+        else:
+            stack, colnorm = st["stack"], st["colnorm"]
+            vals_c, u_t = ops.sort_extract(stack[o_c:o_c + L], colnorm[o_c:o_c + L], kmax)
+            # all eigenvectors are needed by the backward (perturbation couples kept and discarded ones)
+            lam_s, v_all = ops.sort_extract(stack[o_c + L:], colnorm[o_c + L:], n_stud)
         sw = ops.sqrt_clamp(vals_c[:, :kmax])                      # singular values S[:k]   (:36-37)
-        # all eigenvectors are needed by the backward (perturbation couples the kept and the discarded ones)
-        lam_s, v_all = ops.sort_extract(stack[o_c + L:], colnorm[o_c + L:], d_s if want_grad else kmax)
         v_s = v_all[:, :kmax]                                      # (E, kmax, d_s) rows = Vt_s[:kmax]
         proj_s_t = self.proj_s.float().t().contiguous()
         u_rot = ops.gemm_nt(u_t.view(L * kmax, d_s), proj_s_t).view(L, kmax, d_s)   # rows: (proj_s^T u)^T

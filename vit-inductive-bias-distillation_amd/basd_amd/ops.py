@@ -13,8 +13,13 @@ import torch
 
 from . import _lib
 
+import os
+
 F32, BF16 = 0, 1
 MAX_SWEEPS = 20
+# Symmetric eigen-solver for the selector's D_s x D_s Grams when only eigenvalues / leading eigenvectors are
+# needed: "tridiag" (Householder + bisection + inverse iteration) or "jacobi" (block one-sided Jacobi).
+EIG_SOLVER = os.environ.get("BASD_EIG_SOLVER", "tridiag")
 
 
 def _stream() -> int:
@@ -137,6 +142,45 @@ def sym_eig(G: torch.Tensor, kmax: int = 0) -> tuple[torch.Tensor, torch.Tensor 
     colnorm = jacobi_onesided(G, G.shape[1])
     vals, vecs = sort_extract(G, colnorm, kmax)
     return vals, vecs, G, colnorm
+
+
+@dataclass
+class TridiagState:
+    """Householder tridiagonalisation of a batch of symmetric matrices + all eigenvalues (descending)."""
+    d: torch.Tensor
+    e: torch.Tensor
+    tau: torch.Tensor
+    vh: torch.Tensor
+    vals: torch.Tensor      # (batch, n) descending
+
+
+def tridiag_eigenvalues(G: torch.Tensor) -> TridiagState:
+    """G (batch, n, n) symmetric, DESTROYED.  Queues tridiagonalisation + Sturm bisection; no host sync."""
+    _require_cuda(G)
+    assert G.dtype == torch.float32 and G.is_contiguous() and G.dim() == 3 and G.shape[1] == G.shape[2]
+    batch, n, _ = G.shape
+    f32 = dict(device=G.device, dtype=torch.float32)
+    d, e, tau = (torch.empty((batch, n), **f32) for _ in range(3))
+    vh = torch.empty((batch, n, n), **f32)
+    vals = torch.empty((batch, n), **f32)
+    st = _stream()
+    _lib.call("basd_tridiag", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
+              vh.data_ptr(), st)
+    _lib.call("basd_tridiag_eigenvalues", d.data_ptr(), e.data_ptr(), n, batch, vals.data_ptr(), st)
+    return TridiagState(d, e, tau, vh, vals)
+
+
+def tridiag_eigenvectors(ts: TridiagState, k: int, first: int = 0, count: int | None = None) -> torch.Tensor:
+    """Leading k eigenvectors (rows) of matrices [first, first + count) of the batch -> (count, k, n)."""
+    batch, n = ts.vals.shape
+    count = batch - first if count is None else count
+    f32 = dict(device=ts.vals.device, dtype=torch.float32)
+    z = torch.empty((count, k, n), **f32)
+    vecs = torch.empty((count, k, n), **f32)
+    sl = slice(first, first + count)
+    _lib.call("basd_tridiag_eigenvectors", ts.d[sl].data_ptr(), ts.e[sl].data_ptr(), ts.tau[sl].data_ptr(),
+              ts.vh[sl].data_ptr(), ts.vals[sl].data_ptr(), n, k, count, z.data_ptr(), vecs.data_ptr(), k, _stream())
+    return vecs
 
 
 def sort_extract(W: torch.Tensor, colnorm: torch.Tensor, kmax: int, rows: int | None = None):

@@ -37,8 +37,32 @@ __device__ __forceinline__ T group_sum(T v, int width) {
     return v;
 }
 
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) { return group_sum(v, kWave); }
+// ---- cross-lane sums without LDS: DPP inside a row of 16 lanes, lane-swaps across rows -------------
+// (the __shfl_xor forms above go through ds_bpermute: ~100 cycles per step; these are plain VALU ops)
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+// Every lane of an (aligned) row of 16 ends with the row total; all 16 lanes must be active.
+__device__ __forceinline__ float row16_allsum(float x) {
+    x += dpp_get<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_get<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_get<0x141>(x);   // row_half_mirror
+    x += dpp_get<0x140>(x);   // row_mirror
+    return x;
+}
+// Every lane ends with the wave total; ALL 64 lanes must be active (the swaps read the partner's register).
+__device__ __forceinline__ float wave64_allsum(float x) {
+    x = row16_allsum(x);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return wave64_allsum(v); }
+__device__ __forceinline__ int wave_sum(int v) { return group_sum(v, kWave); }
+__device__ __forceinline__ double wave_sum(double v) { return group_sum(v, kWave); }
 
 __device__ __forceinline__ float wave_max(float v) {
     for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));

@@ -63,26 +63,6 @@ __device__ __forceinline__ Rot make_rotation(float alpha, float beta, float gamm
     return r;
 }
 
-// ---- cross-lane sums without LDS: DPP inside a row of 16 lanes, lane-swaps across rows -------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_get(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-// Every lane of an (aligned) row of 16 ends with the row total; all 16 lanes must be active.
-__device__ __forceinline__ float row16_allsum(float x) {
-    x += dpp_get<0xB1>(x);    // quad_perm [1,0,3,2]
-    x += dpp_get<0x4E>(x);    // quad_perm [2,3,0,1]
-    x += dpp_get<0x141>(x);   // row_half_mirror
-    x += dpp_get<0x140>(x);   // row_mirror
-    return x;
-}
-__device__ __forceinline__ float wave64_allsum(float x) {
-    x = row16_allsum(x);
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
 template <int LPP>
 __device__ __forceinline__ float pair_allsum(float x) {
     static_assert(LPP == 16 || LPP == 64, "a pair is owned by one DPP row or one wave");

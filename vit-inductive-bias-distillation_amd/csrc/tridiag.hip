@@ -1,0 +1,505 @@
+// Symmetric eigen-solver for the selector's D_s x D_s Gram matrices when only the eigenvalues and/or the
+// leading k eigenvectors are needed (reference call sites: torch.linalg.eigvalsh layer_selector.py:16;
+// the Vt[:k] / S[:k] part of torch.linalg.svd at :36 and :92):
+//
+//   Householder tridiagonalisation  ->  Sturm-sequence bisection (all eigenvalues)
+//        ->  inverse iteration on T for the top k  ->  back-transformation with the reflectors.
+//
+// Why not the Jacobi solver here: one-sided Jacobi on a 384 x 384 matrix is a chain of ~14 sweeps x 383
+// dependent pair-steps (about 5000 launches-worth of latency); tridiagonalisation is 382 dependent steps.
+// Jacobi stays in use where ALL eigenvectors are needed (backward of multi-layer teachers) and for the
+// small LDS-resident SVDs.
+//
+// One workgroup per matrix; the matrix stays in L2 and is streamed row-wise (coalesced), the Householder
+// vector lives in LDS.  Everything is fp32, like LAPACK's ssytd2 / sstebz / sstein it restates.
+#include "basd_common.h"
+
+namespace basd {
+
+// ---------------------------------------------------------------------------
+// A = Q T Q^T, lower variant: Q = H_0 H_1 ... H_{n-2}, H_j = I - tau_j v_j v_j^T.
+// grid = batch, block = 1024.   A (n x n row-major) is destroyed; d (n), e (n-1), tau (n-1) out;
+// Vh (n x n row-major): row j = v_j (zeros up to j, 1 at j+1), for the back-transformation.
+// ---------------------------------------------------------------------------
+template <bool VEC>
+__global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, long a_batch_stride, int n,
+                                                       float* __restrict__ d, float* __restrict__ e,
+                                                       float* __restrict__ tau_out, float* __restrict__ Vh) {
+    // ONE pass over the trailing block per step: the rank-2 update of step j-1 is applied lazily while the
+    // rows are read for the matrix-vector product of step j (a' = a - v_r w_c - w_r v_c ; p_r += a' u_c), and
+    // the column the next reflector is built from is captured on the way.  All vectors are indexed by ABSOLUTE
+    // row/column (zero below the active block), so the pass runs over 16-byte aligned column chunks.
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* v = sm;             // previous reflector
+    float* w = sm + n;         // its w = p + gamma v
+    float* u = sm + 2 * n;     // current reflector
+    float* pw = sm + 3 * n;    // current p, then current w
+    float* col = sm + 4 * n;   // column j of the up-to-date matrix (rows >= j)
+    __shared__ float red[32];
+    __shared__ float s_tau, s_beta;
+    const int z = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    float* Az = A + (long)z * a_batch_stride;
+    float* dz = d + (long)z * n;
+    float* ez = e + (long)z * n;
+    float* tz = tau_out + (long)z * n;
+    float* Vz = Vh + (long)z * n * n;
+    constexpr int RB = 8;      // rows per wave-iteration: RB independent load streams keep L2 latency covered
+    for (int r = tid; r < n; r += nthr) {
+        v[r] = 0.f;
+        w[r] = 0.f;
+        col[r] = Az[(long)r * n];
+    }
+    __syncthreads();
+    for (int j = 0; j < n - 1; ++j) {
+        const int r0 = j + 1;
+        float part = 0.f;
+        for (int r = r0 + 1 + tid; r < n; r += nthr) part = fmaf(col[r], col[r], part);
+        const float xn2 = block_sum(part, red);
+        const float alpha = col[r0];
+        if (tid == 0) {
+            float tau = 0.f, beta = alpha;
+            if (xn2 > 0.f) {
+                beta = -copysignf(sqrtf(fmaf(alpha, alpha, xn2)), alpha);
+                tau = (beta - alpha) / beta;
+            }
+            s_tau = tau;
+            s_beta = beta;
+            dz[j] = col[j];
+            ez[j] = beta;
+            tz[j] = tau;
+        }
+        __syncthreads();
+        const float tau = s_tau;
+        const float scal = tau != 0.f ? 1.f / (alpha - s_beta) : 0.f;
+        for (int r = tid; r < n; r += nthr) {
+            const float ur = r < r0 ? 0.f : (r == r0 ? 1.f : col[r] * scal);
+            u[r] = ur;
+            Vz[(long)j * n + r] = ur;          // reflector row for the back-transformation
+        }
+        __syncthreads();
+        const int c_begin = VEC ? (r0 & ~3) : r0;
+        for (int rb = r0 + wave * RB; rb < n; rb += nw * RB) {
+            float acc[RB], vr[RB], wr[RB];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                acc[q] = 0.f;
+                vr[q] = rb + q < n ? v[rb + q] : 0.f;
+                wr[q] = rb + q < n ? w[rb + q] : 0.f;
+            }
+            if (VEC) {
+                for (int c = c_begin + 4 * lane; c < n; c += 256) {
+                    const float4 vv = *(const float4*)(v + c), ww = *(const float4*)(w + c);
+                    const float4 uu = *(const float4*)(u + c);
+                    float4 a[RB];
+#pragma unroll
+                    for (int q = 0; q < RB; ++q)
+                        if (rb + q < n) a[q] = *(const float4*)(Az + (long)(rb + q) * n + c);
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        if (rb + q < n) {
+                            a[q].x -= fmaf(vr[q], ww.x, wr[q] * vv.x);
+                            a[q].y -= fmaf(vr[q], ww.y, wr[q] * vv.y);
+                            a[q].z -= fmaf(vr[q], ww.z, wr[q] * vv.z);
+                            a[q].w -= fmaf(vr[q], ww.w, wr[q] * vv.w);
+                            *(float4*)(Az + (long)(rb + q) * n + c) = a[q];
+                            acc[q] = fmaf(a[q].x, uu.x, fmaf(a[q].y, uu.y, fmaf(a[q].z, uu.z, fmaf(a[q].w, uu.w, acc[q]))));
+                            if (c == c_begin) {      // the chunk holding column r0: capture the next column
+                                const int off = r0 - c_begin;
+                                col[rb + q] = off == 0 ? a[q].x : off == 1 ? a[q].y : off == 2 ? a[q].z : a[q].w;
+                            }
+                        }
+                    }
+                }
+            } else {
+                for (int c = c_begin + lane; c < n; c += 64) {
+                    const float vc = v[c], wc = w[c], uc = u[c];
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        if (rb + q < n) {
+                            const float an = Az[(long)(rb + q) * n + c] - fmaf(vr[q], wc, wr[q] * vc);
+                            Az[(long)(rb + q) * n + c] = an;
+                            acc[q] = fmaf(an, uc, acc[q]);
+                            if (c == r0) col[rb + q] = an;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const float sum = wave_sum(acc[q]);
+                if (lane == 0 && rb + q < n) pw[rb + q] = tau * sum;
+            }
+        }
+        __syncthreads();
+        float gp = 0.f;
+        for (int r = r0 + tid; r < n; r += nthr) gp = fmaf(pw[r], u[r], gp);
+        const float gamma = -0.5f * tau * block_sum(gp, red);
+        for (int r = tid; r < n; r += nthr) pw[r] = r >= r0 ? fmaf(gamma, u[r], pw[r]) : 0.f;
+        __syncthreads();
+        // column r0 of the matrix with update j applied; then (u, w_j) become the pending lazy update
+        const float w0 = pw[r0];
+        for (int r = tid; r < n; r += nthr) {
+            if (r >= r0) col[r] -= fmaf(u[r], w0, pw[r]);       // u[r0] = 1
+            v[r] = u[r];
+            w[r] = pw[r];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        dz[n - 1] = col[n - 1];
+        ez[n - 1] = 0.f;
+        tz[n - 1] = 0.f;
+    }
+    for (int c = tid; c < n; c += nthr) Vz[(long)(n - 1) * n + c] = 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// All eigenvalues of the symmetric tridiagonal (d, e) by bisection on the Sturm count (LAPACK sstebz),
+// descending.  grid = batch, block = 256; thread i owns the i-th largest.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) sturm_bisect_kernel(const float* __restrict__ d, const float* __restrict__ e,
+                                                           int n, float* __restrict__ vals_desc) {
+    extern __shared__ float sm[];
+    float* dd = sm;        // n
+    float* e2 = sm + n;    // n (e2[i] = e[i]^2, i < n-1)
+    const int z = blockIdx.x, tid = threadIdx.x;
+    const float* dz = d + (long)z * n;
+    const float* ez = e + (long)z * n;
+    float lo = 3.4e38f, hi = -3.4e38f, emax = 0.f;
+    const int nthr = blockDim.x, nwv = nthr >> 6;
+    for (int i = tid; i < n; i += nthr) {
+        const float di = dz[i];
+        const float el = i > 0 ? fabsf(ez[i - 1]) : 0.f, er = i < n - 1 ? fabsf(ez[i]) : 0.f;
+        dd[i] = di;
+        e2[i] = i < n - 1 ? ez[i] * ez[i] : 0.f;
+        lo = fminf(lo, di - el - er);
+        hi = fmaxf(hi, di + el + er);
+        emax = fmaxf(emax, er * er);
+    }
+    // block min / max
+    lo = -wave_max(-lo);
+    hi = wave_max(hi);
+    emax = wave_max(emax);
+    __syncthreads();
+    __shared__ float red3[3][16];
+    if ((tid & 63) == 0) { red3[0][tid >> 6] = lo; red3[1][tid >> 6] = hi; red3[2][tid >> 6] = emax; }
+    __syncthreads();
+    for (int i = 0; i < nwv; ++i) {
+        lo = fminf(lo, red3[0][i]);
+        hi = fmaxf(hi, red3[1][i]);
+        emax = fmaxf(emax, red3[2][i]);
+    }
+    const float tnorm = fmaxf(fabsf(lo), fabsf(hi));
+    const float eps = 1.1920929e-7f;
+    lo -= 2.f * tnorm * eps * n + 1e-37f;
+    hi += 2.f * tnorm * eps * n + 1e-37f;
+    const float pivmin = fmaxf(1.1754944e-38f * fmaxf(emax, 1.f), 1e-37f);
+    for (int i = tid; i < n; i += nthr) {
+        const int k_asc = n - 1 - i;          // 0-based ascending index of the i-th largest
+        float a = lo, b = hi;
+        for (int it = 0; it < 64; ++it) {
+            const float mid = 0.5f * (a + b);
+            if (mid <= a || mid >= b) break;
+            // number of eigenvalues < mid
+            int cnt = 0;
+            float q = dd[0] - mid;
+            if (fabsf(q) < pivmin) q = -pivmin;
+            cnt += q < 0.f;
+            for (int r = 1; r < n; ++r) {
+                // 1-ulp hardware reciprocal: the count is only ambiguous where q is round-off anyway
+                q = (dd[r] - mid) - e2[r - 1] * __builtin_amdgcn_rcpf(q);
+                if (fabsf(q) < pivmin) q = -pivmin;
+                cnt += q < 0.f;
+            }
+            if (cnt <= k_asc) a = mid; else b = mid;
+            if (b - a <= 2.f * eps * fmaxf(fabsf(a), fabsf(b)) + pivmin) break;
+        }
+        vals_desc[(long)z * n + i] = 0.5f * (a + b);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Top-k eigenvectors of the tridiagonal by inverse iteration (LAPACK sstein / slagtf / slagts), followed by
+// ordered re-orthogonalisation inside clusters of close eigenvalues.  Z out: (k x n) row-major, unit rows.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float hash_unit(unsigned a, unsigned b) {
+    unsigned h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return (float)(h & 0xFFFFFF) * (2.f / 16777216.f) - 1.f;     // (-1, 1)
+}
+
+// shifts actually used: the computed eigenvalues, with (numerically) coincident ones pushed apart
+__device__ __forceinline__ void invit_shifts(const float* __restrict__ vz, int k, float tnorm, float* __restrict__ lam) {
+    const float sep = 10.f * 1.1920929e-7f * tnorm;
+    float prev = 0.f;
+    for (int t = 0; t < k; ++t) {
+        float l = vz[t];
+        if (t > 0 && prev - l < sep) l = prev - sep;
+        lam[t] = l;
+        prev = l;
+    }
+}
+
+__device__ __forceinline__ float tridiag_norm(const float* __restrict__ dz, const float* __restrict__ ez, int n,
+                                              int tid, int nthr, float* red) {
+    float tn = 0.f;
+    for (int i = tid; i < n; i += nthr)
+        tn = fmaxf(tn, fabsf(dz[i]) + (i > 0 ? fabsf(ez[i - 1]) : 0.f) + (i < n - 1 ? fabsf(ez[i]) : 0.f));
+    tn = wave_max(tn);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = tn;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < (nthr + 63) / 64; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+// Phase A.  grid = (ceil(k / vpw), batch), block = 64: thread t of a workgroup owns vector blockIdx.x*vpw + t.
+// The LU factors (a, b, c, d2, pivot flag) and the iterate x live in LDS as [array][element][vector]: the
+// recurrences are sequential in the element index, so what matters is that the operands of step i+1 do not
+// depend on step i's result (they are fetched ahead), leaving a short arithmetic chain per step.
+__global__ void __launch_bounds__(64) tridiag_invit_kernel(const float* __restrict__ d, const float* __restrict__ e,
+                                                           const float* __restrict__ vals_desc, int n, int k, int vpw,
+                                                           float* __restrict__ Z) {
+    extern __shared__ float sm[];
+    __shared__ float red[32];
+    __shared__ float lam_s[1024];
+    const int z = blockIdx.y, tid = threadIdx.x;
+    const float* dz = d + (long)z * n;
+    const float* ez = e + (long)z * n;
+    const float tnorm = tridiag_norm(dz, ez, n, tid, 64, red);
+    if (tid == 0) invit_shifts(vals_desc + (long)z * n, k, tnorm, lam_s);
+    __syncthreads();
+    const int t = blockIdx.x * vpw + tid;
+    if (tid >= vpw || t >= k) return;
+    const float eps = 1.1920929e-7f;
+    const float tol = eps * tnorm + 1e-37f;
+    const long S = (long)n * vpw;                  // array stride
+    float* a = sm + 0 * S + tid;                   // element i at a[i * vpw]
+    float* b = sm + 1 * S + tid;
+    float* c = sm + 2 * S + tid;
+    float* d2 = sm + 3 * S + tid;
+    float* in = sm + 4 * S + tid;
+    float* x = sm + 5 * S + tid;
+    const float l = lam_s[t];
+    for (int i = 0; i < n; ++i) {
+        a[i * vpw] = dz[i] - l;
+        const float ei = i < n - 1 ? ez[i] : 0.f;
+        b[i * vpw] = ei;
+        c[i * vpw] = ei;
+        d2[i * vpw] = 0.f;
+        in[i * vpw] = 0.f;
+        x[i * vpw] = hash_unit((unsigned)i, (unsigned)t);
+    }
+    // slagtf: LU with partial pivoting of the shifted tridiagonal
+    {
+        float ai = a[0];
+        float scale1 = fabsf(ai) + (n > 1 ? fabsf(b[0]) : 0.f);
+        for (int i = 0; i < n - 1; ++i) {
+            const float ci = c[i * vpw], bi = b[i * vpw];
+            const float a1 = a[(i + 1) * vpw];
+            const float b1 = i < n - 2 ? b[(i + 1) * vpw] : 0.f;
+            const float scale2 = fabsf(ci) + fabsf(a1) + fabsf(b1);
+            const float piv1 = ai == 0.f ? 0.f : fabsf(ai) / scale1;
+            const float piv2 = ci == 0.f ? 0.f : fabsf(ci) / scale2;
+            float a_next;
+            if (ci == 0.f || piv2 <= piv1) {
+                const float mult = ci == 0.f ? 0.f : ci / ai;
+                c[i * vpw] = mult;
+                a_next = a1 - mult * bi;
+            } else {
+                in[i * vpw] = 1.f;
+                const float mult = ai / ci;
+                a[i * vpw] = ci;
+                a_next = bi - mult * a1;
+                if (i < n - 2) {
+                    d2[i * vpw] = b1;
+                    b[(i + 1) * vpw] = -mult * b1;
+                }
+                b[i * vpw] = a1;
+                c[i * vpw] = mult;
+            }
+            a[(i + 1) * vpw] = a_next;
+            ai = a_next;
+            scale1 = scale2;
+        }
+    }
+    // inverse iteration: three solves with slagts-style pivot perturbation
+    for (int it = 0; it < 3; ++it) {
+        float nrm1 = 0.f;
+        for (int i = 0; i < n; ++i) nrm1 += fabsf(x[i * vpw]);
+        const float sc1 = (float)n * tnorm * eps / fmaxf(nrm1, 1e-37f);
+        // forward substitution (P L), scaling folded in
+        float prev = x[0] * sc1;
+        for (int i = 1; i < n; ++i) {
+            const float ci = c[(i - 1) * vpw], flag = in[(i - 1) * vpw];
+            const float xi = x[i * vpw] * sc1;
+            float keep, next;
+            if (flag == 0.f) { keep = prev; next = xi - ci * prev; }
+            else { keep = xi; next = prev - ci * xi; }
+            x[(i - 1) * vpw] = keep;
+            prev = next;
+        }
+        x[(n - 1) * vpw] = prev;
+        // back substitution (U)
+        float x1 = 0.f, x2 = 0.f, mx = 0.f;
+        for (int i = n - 1; i >= 0; --i) {
+            float tmp = x[i * vpw] - b[i * vpw] * x1 - d2[i * vpw] * x2;    // b / d2 are 0 past the end
+            float ak = a[i * vpw];
+            if (fabsf(ak) < tol) ak = copysignf(tol, ak == 0.f ? 1.f : ak);
+            tmp /= ak;
+            x[i * vpw] = tmp;
+            mx = fmaxf(mx, fabsf(tmp));
+            x2 = x1;
+            x1 = tmp;
+        }
+        const float inv = 1.f / fmaxf(mx, 1e-37f);
+        float ss = 0.f;
+        for (int i = 0; i < n; ++i) { const float u = x[i * vpw] * inv; ss = fmaf(u, u, ss); }
+        const float sc2 = inv / sqrtf(ss);
+        for (int i = 0; i < n; ++i) x[i * vpw] *= sc2;
+    }
+    float* out = Z + ((long)z * k + t) * n;
+    for (int i = 0; i < n; ++i) out[i] = x[i * vpw];
+}
+
+// Phase B: ordered re-orthogonalisation (two classical Gram-Schmidt passes) inside clusters of eigenvalues
+// closer than 1e-3 ||T|| (LAPACK sstein's criterion).  grid = batch, block = 256.
+__global__ void __launch_bounds__(256) cluster_orth_kernel(const float* __restrict__ d, const float* __restrict__ e,
+                                                           const float* __restrict__ vals_desc, int n, int k,
+                                                           float* __restrict__ Z) {
+    extern __shared__ float sm[];
+    float* lam = sm;            // k
+    float* coef = sm + k;       // k
+    __shared__ float red[32];
+    const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float tnorm = tridiag_norm(d + (long)z * n, e + (long)z * n, n, tid, 256, red);
+    if (tid == 0) invit_shifts(vals_desc + (long)z * n, k, tnorm, lam);
+    __syncthreads();
+    float* Zz = Z + (long)z * k * n;
+    int start = 0;
+    for (int t = 1; t < k; ++t) {
+        if (lam[t - 1] - lam[t] >= 1e-3f * tnorm) { start = t; continue; }
+        float* x = Zz + (long)t * n;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int j = start + wave; j < t; j += 4) {
+                const float* y = Zz + (long)j * n;
+                float s = 0.f;
+                for (int i = lane; i < n; i += 64) s = fmaf(x[i], y[i], s);
+                s = wave_sum(s);
+                if (lane == 0) coef[j] = s;
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) {
+                float acc = x[i];
+                for (int j = start; j < t; ++j) acc = fmaf(-coef[j], Zz[(long)j * n + i], acc);
+                x[i] = acc;
+            }
+            __syncthreads();
+        }
+        float ss = 0.f;
+        for (int i = tid; i < n; i += 256) ss = fmaf(x[i], x[i], ss);
+        ss = block_sum(ss, red);
+        const float inv = 1.f / sqrtf(fmaxf(ss, 1e-37f));
+        for (int i = tid; i < n; i += 256) x[i] *= inv;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Eigenvectors of A from those of T:  x = H_0 H_1 ... H_{n-2} z.   One wave per vector, the vector in
+// registers (n <= 64 * EPL).  grid = (ceil(k/4), batch), block = 256.  out: (k x n) rows.
+// ---------------------------------------------------------------------------
+template <int EPL>
+__global__ void __launch_bounds__(256) backtransform_kernel(const float* __restrict__ Vh,
+                                                            const float* __restrict__ tau, int n, int k,
+                                                            const float* __restrict__ Z, float* __restrict__ out,
+                                                            int out_stride_k) {
+    const int z = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= k) return;
+    const float* Vz = Vh + (long)z * n * n;
+    const float* tz = tau + (long)z * n;
+    const float* zz = Z + ((long)z * k + t) * n;
+    float x[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int r = lane + 64 * i;
+        x[i] = r < n ? zz[r] : 0.f;
+    }
+    for (int j = n - 2; j >= 0; --j) {
+        const float tj = tz[j];
+        if (tj == 0.f) continue;
+        const float* vj = Vz + (long)j * n;
+        float vr[EPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            const int r = lane + 64 * i;
+            vr[i] = r < n ? vj[r] : 0.f;
+            s = fmaf(vr[i], x[i], s);
+        }
+        s = wave_sum(s) * tj;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) x[i] = fmaf(-s, vr[i], x[i]);
+    }
+    float* o = out + ((long)z * out_stride_k + t) * n;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int r = lane + 64 * i;
+        if (r < n) o[r] = x[i];
+    }
+}
+
+}  // namespace basd
+
+using namespace basd;
+
+extern "C" {
+
+// Householder tridiagonalisation of `batch` symmetric matrices (destroyed).  d, e, tau: (batch, n);
+// vh: (batch, n, n) reflector rows.
+int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
+                 hipStream_t stream) {
+    BASD_CHECK_ARG(a && d && e && tau && vh && n > 1 && batch > 0);
+    if (n > 4096) return BASD_EUNSUPPORTED;
+    const bool vec = (n & 3) == 0 && (a_batch_stride & 3) == 0 && (((uintptr_t)a) & 15) == 0;
+    if (vec) tridiag_kernel<true><<<batch, 1024, sizeof(float) * 5 * (size_t)n, stream>>>(a, a_batch_stride, n, d, e, tau, vh);
+    else tridiag_kernel<false><<<batch, 1024, sizeof(float) * 5 * (size_t)n, stream>>>(a, a_batch_stride, n, d, e, tau, vh);
+    BASD_RETURN_LAST();
+}
+
+// All eigenvalues (descending) of the tridiagonals by Sturm bisection.
+int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, float* vals_desc, hipStream_t stream) {
+    BASD_CHECK_ARG(d && e && vals_desc && n > 0 && batch > 0);
+    if (n > 8192) return BASD_EUNSUPPORTED;
+    int threads = ((n + 63) / 64) * 64;
+    if (threads > 1024) threads = 1024;
+    sturm_bisect_kernel<<<batch, threads, sizeof(float) * 2 * (size_t)n, stream>>>(d, e, n, vals_desc);
+    BASD_RETURN_LAST();
+}
+
+// Top-k eigenvectors of the ORIGINAL matrices (rows of vecs: (batch, k_stride, n), first k rows written).
+// z: batch * k * n floats of scratch (eigenvectors of the tridiagonals).
+int basd_tridiag_eigenvectors(const float* d, const float* e, const float* tau, const float* vh,
+                              const float* vals_desc, int n, int k, int batch, float* z, float* vecs, int k_stride,
+                              hipStream_t stream) {
+    BASD_CHECK_ARG(d && e && tau && vh && vals_desc && z && vecs && n > 1 && k > 0 && k <= n && batch > 0);
+    BASD_CHECK_ARG(k_stride >= k && k <= 1024);
+    int vpw = (int)((144 * 1024) / (6 * sizeof(float) * (size_t)n));
+    if (vpw > 64) vpw = 64;
+    if (vpw < 1) return BASD_EUNSUPPORTED;
+    const size_t lds_a = sizeof(float) * 6 * (size_t)n * vpw;
+    if (lds_a > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)tridiag_invit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+    tridiag_invit_kernel<<<dim3((k + vpw - 1) / vpw, batch), 64, lds_a, stream>>>(d, e, vals_desc, n, k, vpw, z);
+    cluster_orth_kernel<<<batch, 256, sizeof(float) * 2 * (size_t)k, stream>>>(d, e, vals_desc, n, k, z);
+    const dim3 grid((k + 3) / 4, batch);
+    if (n <= 192) backtransform_kernel<3><<<grid, 256, 0, stream>>>(vh, tau, n, k, z, vecs, k_stride);
+    else if (n <= 384) backtransform_kernel<6><<<grid, 256, 0, stream>>>(vh, tau, n, k, z, vecs, k_stride);
+    else if (n <= 768) backtransform_kernel<12><<<grid, 256, 0, stream>>>(vh, tau, n, k, z, vecs, k_stride);
+    else if (n <= 1024) backtransform_kernel<16><<<grid, 256, 0, stream>>>(vh, tau, n, k, z, vecs, k_stride);
+    else return BASD_EUNSUPPORTED;
+    BASD_RETURN_LAST();
+}
+
+}  // extern "C"
