@@ -226,3 +226,31 @@ def test_cfg2_full_size(golden):
     comp = mod.last_components
     ce, geo = comp["ce"].item(), comp["geo_layers"].mean().item()
     assert abs(loss.item() - 2 * ce * geo / (ce + geo)) < 1e-4 * loss.item()
+
+
+def test_bf16_inputs_cfg5_shapes():
+    """cfg-5 (bf16 features): tokens are consumed in place as bf16 and widened inside the kernels; the parity
+    target is the fp32 oracle on the same bf16-rounded values (the reference itself has no runnable
+    bf16-input CPU path: its selector matmul mixes dtypes)."""
+    shape = synth.CONFIGS["cfg5"]
+    mod = _module(shape, 0.001)
+    inp = synth.make_inputs(shape, 77, batch=4, device=DEV, dtype=torch.bfloat16, strided=True)
+    leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
+    loss = mod(inp.logits, inp.targets, leaves, inp.teacher, inp.attn)
+    loss.backward()
+    torch.manual_seed(42)
+    state = O.SelectorState.create(shape.points, shape.d_s, shape.d_t)
+    cpu = synth.make_inputs(shape, 77, batch=4, dtype=torch.bfloat16)
+    st = {k: v.float().requires_grad_(True) for k, v in cpu.student.items()}
+    te = {k: v.float() for k, v in cpu.teacher.items()}
+    at = {k: v.float() for k, v in cpu.attn.items()}
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.001)
+    ref, trace = O.basd_forward(state, crit, mod.token_layers, shape.n_s, shape.has_cls, cpu.logits, cpu.targets,
+                                st, te, at)
+    ref.backward()
+    assert mod.layer_selector.subspace_ranks == trace.selector.ranks
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+    for l in mod.token_layers:
+        assert leaves[l].grad.dtype == torch.bfloat16
+        g, r = leaves[l].grad.float().cpu(), st[l].grad
+        assert ((g - r).norm() / r.norm()).item() < 1e-2       # the gradient itself is rounded to bf16

@@ -320,13 +320,14 @@ class GrassmannianLayerSelector(nn.Module):
         if st["tri"]:
             ts = st["ts"]
             vals_c = ts.vals[o_c:o_c + L]
-            u_t = ops.tridiag_eigenvectors(ts, kmax, first=o_c, count=L)                 # (L, kmax, d_s)
             if st["stud_jacobi"]:
+                u_t = ops.tridiag_eigenvectors(ts, kmax, first=o_c, count=L)             # (L, kmax, d_s)
                 lam_s, v_all = ops.sort_extract(st["s_stack"], st["s_colnorm"], n_stud)
             else:
                 assert not want_grad
+                both = ops.tridiag_eigenvectors(ts, kmax, first=o_c, count=L + E)        # one call: teacher + student
+                u_t, v_all = both[:L], both[L:]
                 lam_s = ts.vals[o_c + L:]
-                v_all = ops.tridiag_eigenvectors(ts, kmax, first=o_c + L, count=E)
         else:
             stack, colnorm = st["stack"], st["colnorm"]
             vals_c, u_t = ops.sort_extract(stack[o_c:o_c + L], colnorm[o_c:o_c + L], kmax)
