@@ -138,8 +138,9 @@ def main() -> None:
 
     for _ in range(args.warmup):
         loss = step()
-    # dominant kernel (one-sided Jacobi SVD of the stacked Procrustes core): HIP events on its stream
-    dominant = "basd_jacobi_onesided"
+    # dominant kernel: tridiag_kernel (Householder tridiagonalisation of the selector's Gram matrices; the
+    # entry point basd_tridiag is exactly one launch).  HIP events are recorded on the stream it is queued on.
+    dominant = "basd_tridiag" if ops.EIG_SOLVER == "tridiag" else "basd_jacobi_onesided"
     _lib.timing = {}
     _lib.timed_names = None if args.breakdown else {dominant}
     torch.cuda.synchronize()
@@ -171,18 +172,24 @@ def main() -> None:
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         ab = algorithmic_bytes(shape, batch)
-        # Dominant kernel: jacobi_block_round_kernel, the per-round launch of the block Jacobi eigen-solver
-        # (all 2L + E symmetric D_s x D_s eigen-problems of a step in one entry-point call).  That call is the
-        # longest basd_jacobi_onesided span of every step; it issues MAX_SWEEPS * (nblk - 1) launches.
         spans = sorted(per_call.get(dominant, [0.0]))
-        calls_per_step = max(1, len(spans) // max(1, args.steps))
+        d_s = shape.d_s
+        if dominant == "basd_tridiag":
+            # two launches per step (teacher matrices, student matrices) on two streams; take the student one
+            # (E matrices; the longer).  Algorithmic bytes of a launch: every matrix read once, its reflectors
+            # written once.
+            launches = 1
+            n_mats = shape.points
+            kernel_name = "tridiag_kernel (Householder tridiagonalisation of the E student Gram matrices)"
+            note = "per-CU L2 latency/issue bound: one workgroup per matrix, 383 dependent steps (DESIGN.md section 5)"
+        else:
+            nblk = ((d_s + 15) // 16 + 1) // 2 * 2
+            launches = ops.MAX_SWEEPS * (nblk - 1)
+            n_mats = 2 * shape.layers_t + shape.points
+            kernel_name = "jacobi_block_round_kernel (block one-sided Jacobi, symmetric eigen-solves of the selector)"
+            note = "latency-bound chain of dependent pair-steps, not an HBM stream (DESIGN.md section 5)"
         eig = spans[-args.steps:] if len(spans) >= args.steps else spans
         eig_ms = sum(eig) / max(1, len(eig))
-        d_s = shape.d_s
-        nblk = ((d_s + 15) // 16 + 1) // 2 * 2
-        launches = ops.MAX_SWEEPS * (nblk - 1) if d_s * (d_s + 4) * 4 > 156 * 1024 else 1
-        n_mats = 2 * shape.layers_t + shape.points
-        # algorithmic bytes of the solve: every Gram matrix read once, its rotated image written once
         solve_bytes = n_mats * 2 * d_s * d_s * 4
         launch_ms = eig_ms / launches
         launch_bytes = solve_bytes / launches
@@ -218,12 +225,12 @@ def main() -> None:
                 "frac_of_8TBps": ab["step"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             "roofline": {
-                "kernel": "jacobi_block_round_kernel (block one-sided Jacobi, symmetric eigen-solves of the selector)",
+                "kernel": kernel_name,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "launch_ms": launch_ms, "launches_per_step": launches, "solve_ms_per_step": eig_ms,
                 "algorithmic_bytes_per_launch": launch_bytes,
-                "note": "latency-bound chain of dependent pair-steps, not an HBM stream (DESIGN.md section 5)",
+                "note": note,
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -248,52 +248,61 @@ class GrassmannianLayerSelector(nn.Module):
     # ---- distances + mixing weights ------------------------------------------------------
     @torch.no_grad()
     def _spectra_async(self, students: list[torch.Tensor], teachers: list[torch.Tensor],
-                       all_student_vectors: bool = False) -> dict:
-        """Queue every Gram matrix and eigen-solve of the step on the current stream; no host sync.
+                       all_student_vectors: bool = False, student_stream=None) -> dict:
+        """Queue every Gram matrix and eigen-solve of the step; no host sync.
         (layer_selector.py:69-74, :131-138, :86-92)
 
         Solver choice: the teacher matrices need eigenvalues (MP rank) and the leading k eigenvectors, the
         student matrices the leading k eigenvectors -- tridiagonalisation + bisection + inverse iteration.
-        Only the backward of multi-layer teachers needs ALL student eigenvectors: those go through Jacobi."""
+        Only the backward of multi-layer teachers needs ALL student eigenvectors: those go through Jacobi.
+
+        The teacher chain runs on the current stream; with ``student_stream`` the (independent) student chain
+        is queued there, so the latency-bound eigen-solves of the two sides overlap."""
         d_s = self.student_dim
         E, L = len(students), len(teachers)
         dev = students[0].device
-        g_u, g_c, M = self._teacher_grams(teachers)
-        same = g_u.shape[1] == d_s
         tri = ops.EIG_SOLVER == "tridiag"
         stud_jacobi = all_student_vectors or not tri
-        # one batched solver call per solver: [teacher uncentred (L) | teacher centred (L) | student centred (E)]
-        n_main = (2 * L if same else L) + (0 if (tri and stud_jacobi) else E)
-        stack = torch.empty((n_main, d_s, d_s), device=dev, dtype=torch.float32)
-        s_stack = torch.empty((E, d_s, d_s), device=dev, dtype=torch.float32) if (tri and stud_jacobi) else None
-        o_c = L if same else 0
-        if same:
-            stack[:L] = g_u
-        stack[o_c:o_c + L] = g_c
-        means = []
-        for e, x in enumerate(students):
-            x = ops.as_supported(x)
-            mean = ops.colmean(x)
-            means.append(mean)
-            # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
-            # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
-            gram = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
-            if s_stack is not None:
-                s_stack[e] = gram
-            else:
-                stack[o_c + L + e] = gram
-        st = dict(o_c=o_c, E=E, L=L, means=means, tri=tri, stud_jacobi=stud_jacobi)
-        if tri:
-            ts = ops.tridiag_eigenvalues(stack)
-            st["ts"] = ts
-            vals_u = ts.vals[:L] if same else ops.tridiag_eigenvalues(g_u).vals
-            if s_stack is not None:
+        st = dict(E=E, L=L, tri=tri, stud_jacobi=stud_jacobi, student_stream=student_stream)
+
+        # ---- student side: centred Grams -> eigen-solve ----
+        cur = torch.cuda.current_stream()
+        if student_stream is not None:
+            student_stream.wait_stream(cur)
+        with torch.cuda.stream(student_stream if student_stream is not None else cur):
+            s_stack = torch.empty((E, d_s, d_s), device=dev, dtype=torch.float32)
+            means = []
+            for e, x in enumerate(students):
+                x = ops.as_supported(x)
+                mean = ops.colmean(x)
+                means.append(mean)
+                # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
+                # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
+                s_stack[e] = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
+            st["means"] = means
+            if stud_jacobi:
                 st["s_stack"], st["s_colnorm"] = s_stack, ops.jacobi_onesided(s_stack, d_s)
+            else:
+                st["s_ts"] = ops.tridiag_eigenvalues(s_stack)
+
+        # ---- teacher side: projection, Grams, eigen-solve, MP ranks ----
+        g_u, g_c, M = self._teacher_grams(teachers)
+        same = g_u.shape[1] == d_s
+        o_c = L if same else 0
+        t_stack = torch.empty((o_c + L, d_s, d_s), device=dev, dtype=torch.float32)
+        if same:
+            t_stack[:L] = g_u
+        t_stack[o_c:] = g_c
+        st["o_c"] = o_c
+        if tri:
+            ts = ops.tridiag_eigenvalues(t_stack)
+            st["t_ts"] = ts
+            vals_u = ts.vals[:L] if same else ops.tridiag_eigenvalues(g_u).vals
         else:
-            colnorm = ops.jacobi_onesided(stack, d_s)
-            st["stack"], st["colnorm"] = stack, colnorm
+            colnorm = ops.jacobi_onesided(t_stack, d_s)
+            st["t_stack"], st["t_colnorm"] = t_stack, colnorm
             if same:
-                vals_u, _ = ops.sort_extract(stack[:L], colnorm[:L], 0)
+                vals_u, _ = ops.sort_extract(t_stack[:L], colnorm[:L], 0)
             else:
                 vals_u, _, _, _ = ops.sym_eig(g_u)
         st["ranks_dev"] = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
@@ -317,22 +326,27 @@ class GrassmannianLayerSelector(nn.Module):
                 "non-finite values (a teacher layer has Marchenko-Pastur rank 0).")
         kmax = max(ranks)
         n_stud = d_s if want_grad else kmax
-        if st["tri"]:
-            ts = st["ts"]
-            vals_c = ts.vals[o_c:o_c + L]
+        # student eigenvectors (on the student chain's stream when there is one)
+        ss = st["student_stream"]
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(ss if ss is not None else cur):
             if st["stud_jacobi"]:
-                u_t = ops.tridiag_eigenvectors(ts, kmax, first=o_c, count=L)             # (L, kmax, d_s)
                 lam_s, v_all = ops.sort_extract(st["s_stack"], st["s_colnorm"], n_stud)
             else:
                 assert not want_grad
-                both = ops.tridiag_eigenvectors(ts, kmax, first=o_c, count=L + E)        # one call: teacher + student
-                u_t, v_all = both[:L], both[L:]
-                lam_s = ts.vals[o_c + L:]
+                lam_s = st["s_ts"].vals
+                v_all = ops.tridiag_eigenvectors(st["s_ts"], kmax)
+        # teacher eigenvectors
+        if st["tri"]:
+            ts = st["t_ts"]
+            vals_c = ts.vals[o_c:o_c + L]
+            u_t = ops.tridiag_eigenvectors(ts, kmax, first=o_c, count=L)                 # (L, kmax, d_s)
         else:
-            stack, colnorm = st["stack"], st["colnorm"]
-            vals_c, u_t = ops.sort_extract(stack[o_c:o_c + L], colnorm[o_c:o_c + L], kmax)
-            # all eigenvectors are needed by the backward (perturbation couples kept and discarded ones)
-            lam_s, v_all = ops.sort_extract(stack[o_c + L:], colnorm[o_c + L:], n_stud)
+            vals_c, u_t = ops.sort_extract(st["t_stack"][o_c:o_c + L], st["t_colnorm"][o_c:o_c + L], kmax)
+        if ss is not None:
+            cur.wait_stream(ss)
+            for t in (lam_s, v_all):          # allocated on the student stream, consumed on this one
+                t.record_stream(cur)
         sw = ops.sqrt_clamp(vals_c[:, :kmax])                      # singular values S[:k]   (:36-37)
         v_s = v_all[:, :kmax]                                      # (E, kmax, d_s) rows = Vt_s[:kmax]
         proj_s_t = self.proj_s.float().t().contiguous()
@@ -452,8 +466,8 @@ class BASDLoss(nn.Module):
         self.last_components: dict[str, torch.Tensor] = {}
         self._side_streams: dict = {}
 
-    def _selector_stream(self, device) -> "torch.cuda.Stream":
-        key = str(device)
+    def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
+        key = (str(device), index)
         if key not in self._side_streams:
             self._side_streams[key] = torch.cuda.Stream(device=device)
         return self._side_streams[key]
@@ -487,8 +501,9 @@ class BASDLoss(nn.Module):
             main = torch.cuda.current_stream()
             side = self._selector_stream(main.device)
             side.wait_stream(main)
+            side2 = self._selector_stream(main.device, 1)
             with torch.cuda.stream(side):
-                spectra = sel._spectra_async(students, teachers)
+                spectra = sel._spectra_async(students, teachers, student_stream=side2)
             tau = sel.temperatures.float()
             mix = torch.softmax(torch.zeros((len(students), 1), device=tau.device) / tau.unsqueeze(1), dim=1)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)

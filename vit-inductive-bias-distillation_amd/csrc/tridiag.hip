@@ -21,6 +21,21 @@ namespace basd {
 // grid = batch, block = 1024.   A (n x n row-major) is destroyed; d (n), e (n-1), tau (n-1) out;
 // Vh (n x n row-major): row j = v_j (zeros up to j, 1 at j+1), for the back-transformation.
 // ---------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only: global stores (reflector rows, updated matrix rows) stay in
+// flight across it.  That is sufficient here because every matrix row is always read and written by the SAME
+// wave (static row ownership below), whose own accesses to an address are served in issue order.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ float block_sum_lds(float v, float* scratch, int nw) {
+    v = wave_sum(v);
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    lds_barrier();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, long a_batch_stride, int n,
                                                        float* __restrict__ d, float* __restrict__ e,
@@ -43,7 +58,8 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
     float* ez = e + (long)z * n;
     float* tz = tau_out + (long)z * n;
     float* Vz = Vh + (long)z * n * n;
-    constexpr int RB = 8;      // rows per wave-iteration: RB independent load streams keep L2 latency covered
+    constexpr int RB = 8;      // rows per group: RB independent load streams keep L2 latency covered;
+                               // group g (rows g*RB ..) belongs to wave g % nw for the whole factorisation
     for (int r = tid; r < n; r += nthr) {
         v[r] = 0.f;
         w[r] = 0.f;
@@ -54,7 +70,7 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         const int r0 = j + 1;
         float part = 0.f;
         for (int r = r0 + 1 + tid; r < n; r += nthr) part = fmaf(col[r], col[r], part);
-        const float xn2 = block_sum(part, red);
+        const float xn2 = block_sum_lds(part, red, nw);
         const float alpha = col[r0];
         if (tid == 0) {
             float tau = 0.f, beta = alpha;
@@ -68,7 +84,7 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
             ez[j] = beta;
             tz[j] = tau;
         }
-        __syncthreads();
+        lds_barrier();
         const float tau = s_tau;
         const float scal = tau != 0.f ? 1.f / (alpha - s_beta) : 0.f;
         for (int r = tid; r < n; r += nthr) {
@@ -76,15 +92,19 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
             u[r] = ur;
             Vz[(long)j * n + r] = ur;          // reflector row for the back-transformation
         }
-        __syncthreads();
+        lds_barrier();
         const int c_begin = VEC ? (r0 & ~3) : r0;
-        for (int rb = r0 + wave * RB; rb < n; rb += nw * RB) {
+        const int g_first = r0 / RB;
+        for (int g = g_first + ((wave - g_first % nw + nw) % nw); g * RB < n; g += nw) {
+            const int rb = g * RB;
             float acc[RB], vr[RB], wr[RB];
+            bool live[RB];
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
+                live[q] = rb + q >= r0 && rb + q < n;
                 acc[q] = 0.f;
-                vr[q] = rb + q < n ? v[rb + q] : 0.f;
-                wr[q] = rb + q < n ? w[rb + q] : 0.f;
+                vr[q] = live[q] ? v[rb + q] : 0.f;
+                wr[q] = live[q] ? w[rb + q] : 0.f;
             }
             if (VEC) {
                 for (int c = c_begin + 4 * lane; c < n; c += 256) {
@@ -93,10 +113,10 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
                     float4 a[RB];
 #pragma unroll
                     for (int q = 0; q < RB; ++q)
-                        if (rb + q < n) a[q] = *(const float4*)(Az + (long)(rb + q) * n + c);
+                        if (live[q]) a[q] = *(const float4*)(Az + (long)(rb + q) * n + c);
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
-                        if (rb + q < n) {
+                        if (live[q]) {
                             a[q].x -= fmaf(vr[q], ww.x, wr[q] * vv.x);
                             a[q].y -= fmaf(vr[q], ww.y, wr[q] * vv.y);
                             a[q].z -= fmaf(vr[q], ww.z, wr[q] * vv.z);
@@ -115,7 +135,7 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
                     const float vc = v[c], wc = w[c], uc = u[c];
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
-                        if (rb + q < n) {
+                        if (live[q]) {
                             const float an = Az[(long)(rb + q) * n + c] - fmaf(vr[q], wc, wr[q] * vc);
                             Az[(long)(rb + q) * n + c] = an;
                             acc[q] = fmaf(an, uc, acc[q]);
@@ -127,24 +147,27 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
                 const float sum = wave_sum(acc[q]);
-                if (lane == 0 && rb + q < n) pw[rb + q] = tau * sum;
+                if (lane == 0 && live[q]) pw[rb + q] = tau * sum;
             }
         }
-        __syncthreads();
+        lds_barrier();
         float gp = 0.f;
         for (int r = r0 + tid; r < n; r += nthr) gp = fmaf(pw[r], u[r], gp);
-        const float gamma = -0.5f * tau * block_sum(gp, red);
-        for (int r = tid; r < n; r += nthr) pw[r] = r >= r0 ? fmaf(gamma, u[r], pw[r]) : 0.f;
-        __syncthreads();
-        // column r0 of the matrix with update j applied; then (u, w_j) become the pending lazy update
-        const float w0 = pw[r0];
+        const float gamma = -0.5f * tau * block_sum_lds(gp, red, nw);
+        const float w0 = fmaf(gamma, u[r0], pw[r0]);
+        lds_barrier();                                   // everybody has read pw[r0] before it is rewritten
+        // w_j = p + gamma u; column r0 of the matrix with update j applied; (u, w_j) become the pending update
         for (int r = tid; r < n; r += nthr) {
-            if (r >= r0) col[r] -= fmaf(u[r], w0, pw[r]);       // u[r0] = 1
-            v[r] = u[r];
-            w[r] = pw[r];
+            const float ur = u[r];
+            const float wn = r >= r0 ? fmaf(gamma, ur, pw[r]) : 0.f;
+            if (r >= r0) col[r] -= fmaf(ur, w0, wn);     // u[r0] = 1
+            v[r] = ur;
+            w[r] = wn;
+            pw[r] = wn;
         }
-        __syncthreads();
+        lds_barrier();
     }
+    __syncthreads();
     if (tid == 0) {
         dz[n - 1] = col[n - 1];
         ez[n - 1] = 0.f;
