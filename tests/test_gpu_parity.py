@@ -254,3 +254,39 @@ def test_bf16_inputs_cfg5_shapes():
         assert leaves[l].grad.dtype == torch.bfloat16
         g, r = leaves[l].grad.float().cpu(), st[l].grad
         assert ((g - r).norm() / r.norm()).item() < 1e-2       # the gradient itself is rounded to bf16
+
+
+def test_rank_zero_raises_like_the_reference():
+    """A teacher whose projected Gram has a flat spectrum has Marchenko-Pastur rank 0 (no eigenvalue exceeds
+    median * (1 + sqrt(q))^2); the reference then produces NaN mixing weights and torch.linalg.svd raises
+    LinAlgError.  Same class here, and the oracle agrees on the rank."""
+    shape = synth.LossShape("flat", 4, 16, 32, 12, 16, 48, 1, 1, False, 10)
+    mod = _module(shape, 0.0)
+    gen = torch.Generator().manual_seed(1)
+    B = 8
+    q, _ = torch.linalg.qr(torch.randn(B * 16, 48, generator=gen))      # orthonormal columns: T^T T = I
+    teacher_cpu = q.reshape(B, 16, 48).contiguous()
+    assert O.mp_rank(teacher_cpu.reshape(-1, 48) @ mod.layer_selector.proj_t.cpu().T) == 0
+    student = {l: synth.structured(gen, B, 16, 32, 4).to(DEV) for l in mod.token_layers}
+    teacher = {0: teacher_cpu.to(DEV)}
+    attn = {0: (torch.ones(B, 1, 16, 16) / 16).to(DEV)}
+    logits = torch.randn(B, 10, generator=gen).to(DEV)
+    targets = torch.randint(0, 10, (B,), generator=gen).to(DEV)
+    with pytest.raises(torch.linalg.LinAlgError):
+        mod(logits, targets, student, teacher, attn)
+    assert mod.layer_selector.subspace_ranks == {0: 0}
+
+
+def test_selector_forward_api_materialises_mixed_tensors(golden):
+    """GrassmannianLayerSelector.forward keeps the reference's return contract (dicts of mixed tokens and
+    attention maps); values against the reference's own outputs."""
+    g = golden("selector_outputs.npz")
+    shape, seed = S.SMALL["vit"]
+    mod = _module(shape, 0.01)
+    inp = synth.make_inputs(shape, seed, device=DEV)
+    with torch.no_grad():
+        mixed, mixed_attn = mod.layer_selector(inp.student, inp.teacher, inp.attn, mod.token_layers)
+    for l in mod.token_layers:
+        assert mixed[l].shape == inp.teacher[0].shape and mixed_attn[l].shape == inp.attn[0].shape
+        np.testing.assert_allclose(mixed[l][:, :5, :7].cpu().numpy(), g[f"mixed_{l}_slice"], rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(mixed_attn[l][:, :, 0, 1:].cpu().numpy(), g[f"attn_{l}_cls_row"], rtol=2e-3, atol=1e-6)

@@ -500,8 +500,13 @@ class BASDLoss(nn.Module):
             # bound chains of small launches; run them on a side stream underneath the Procrustes kernels.
             main = torch.cuda.current_stream()
             side = self._selector_stream(main.device)
-            side.wait_stream(main)
             side2 = self._selector_stream(main.device, 1)
+            side.wait_stream(main)
+            # the borrowed inputs are read on the side streams after this call has returned (the tail of the
+            # selector is not joined into the main stream: nothing downstream of it feeds the loss)
+            for t in (*students, *teachers):
+                t.record_stream(side)
+                t.record_stream(side2)
             with torch.cuda.stream(side):
                 spectra = sel._spectra_async(students, teachers, student_stream=side2)
             tau = sel.temperatures.float()
@@ -509,7 +514,6 @@ class BASDLoss(nn.Module):
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
             with torch.cuda.stream(side):
                 sel._angles_from_spectra(spectra, keys)    # host reads the ranks; raises on rank 0 like the reference
-            main.wait_stream(side)
         else:
             mix = sel.mixing_weights(students, keys, teachers)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
