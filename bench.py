@@ -109,7 +109,7 @@ def main() -> None:
     ap.add_argument("--contiguous", action="store_true", help="contiguous inputs instead of the callers' strided views")
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point time table to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=16)
+    ap.add_argument("--cpu-sample-batch", type=int, default=64)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
