@@ -177,19 +177,29 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
 }
 
 // ---------------------------------------------------------------------------
-// All eigenvalues of the symmetric tridiagonal (d, e) by bisection on the Sturm count (LAPACK sstebz),
-// descending.  grid = batch, block = 256; thread i owns the i-th largest.
+// All eigenvalues of the symmetric tridiagonal (d, e) from Sturm counts (LAPACK sstebz), descending.
+// A Sturm count is a chain of n dependent steps, so plain bisection costs ~45 chains per eigenvalue; here
+// every eigenvalue is owned by one DPP row of 16 lanes that evaluates 16 interior points of its bracket per
+// pass (17-section): ~8 passes instead of 45.  grid = (ceil(n/64), batch), block = 1024 = 64 eigenvalues x 16.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float row16_allmax(float x) {
+    x = fmaxf(x, dpp_get<0xB1>(x));
+    x = fmaxf(x, dpp_get<0x4E>(x));
+    x = fmaxf(x, dpp_get<0x141>(x));
+    x = fmaxf(x, dpp_get<0x140>(x));
+    return x;
+}
+
 __global__ void __launch_bounds__(1024) sturm_bisect_kernel(const float* __restrict__ d, const float* __restrict__ e,
-                                                           int n, float* __restrict__ vals_desc) {
+                                                            int n, float* __restrict__ vals_desc) {
     extern __shared__ float sm[];
     float* dd = sm;        // n
     float* e2 = sm + n;    // n (e2[i] = e[i]^2, i < n-1)
-    const int z = blockIdx.x, tid = threadIdx.x;
+    __shared__ float red3[3][16];
+    const int z = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
     const float* dz = d + (long)z * n;
     const float* ez = e + (long)z * n;
     float lo = 3.4e38f, hi = -3.4e38f, emax = 0.f;
-    const int nthr = blockDim.x, nwv = nthr >> 6;
     for (int i = tid; i < n; i += nthr) {
         const float di = dz[i];
         const float el = i > 0 ? fabsf(ez[i - 1]) : 0.f, er = i < n - 1 ? fabsf(ez[i]) : 0.f;
@@ -199,12 +209,10 @@ __global__ void __launch_bounds__(1024) sturm_bisect_kernel(const float* __restr
         hi = fmaxf(hi, di + el + er);
         emax = fmaxf(emax, er * er);
     }
-    // block min / max
     lo = -wave_max(-lo);
     hi = wave_max(hi);
     emax = wave_max(emax);
     __syncthreads();
-    __shared__ float red3[3][16];
     if ((tid & 63) == 0) { red3[0][tid >> 6] = lo; red3[1][tid >> 6] = hi; red3[2][tid >> 6] = emax; }
     __syncthreads();
     for (int i = 0; i < nwv; ++i) {
@@ -217,28 +225,35 @@ __global__ void __launch_bounds__(1024) sturm_bisect_kernel(const float* __restr
     lo -= 2.f * tnorm * eps * n + 1e-37f;
     hi += 2.f * tnorm * eps * n + 1e-37f;
     const float pivmin = fmaxf(1.1754944e-38f * fmaxf(emax, 1.f), 1e-37f);
-    for (int i = tid; i < n; i += nthr) {
-        const int k_asc = n - 1 - i;          // 0-based ascending index of the i-th largest
-        float a = lo, b = hi;
-        for (int it = 0; it < 64; ++it) {
-            const float mid = 0.5f * (a + b);
-            if (mid <= a || mid >= b) break;
-            // number of eigenvalues < mid
-            int cnt = 0;
-            float q = dd[0] - mid;
+
+    const int row = tid >> 4, sub = tid & 15;             // 64 eigenvalues per workgroup, 16 lanes each
+    const int i = blockIdx.x * 64 + row;                  // descending index of this row's eigenvalue
+    const bool live = i < n;
+    const int k_asc = n - 1 - (live ? i : n - 1);         // 0-based ascending index
+    float a = lo, b = hi;
+    for (int it = 0; it < 40; ++it) {
+        // 16 interior points of [a, b]; every lane of the row runs one Sturm count
+        const float x = a + (b - a) * ((float)(sub + 1) * (1.f / 17.f));
+        int cnt = 0;
+        float q = dd[0] - x;
+        if (fabsf(q) < pivmin) q = -pivmin;
+        cnt += q < 0.f;
+        for (int r = 1; r < n; ++r) {
+            // 1-ulp hardware reciprocal: the count is only ambiguous where q is round-off anyway
+            q = (dd[r] - x) - e2[r - 1] * __builtin_amdgcn_rcpf(q);
             if (fabsf(q) < pivmin) q = -pivmin;
             cnt += q < 0.f;
-            for (int r = 1; r < n; ++r) {
-                // 1-ulp hardware reciprocal: the count is only ambiguous where q is round-off anyway
-                q = (dd[r] - mid) - e2[r - 1] * __builtin_amdgcn_rcpf(q);
-                if (fabsf(q) < pivmin) q = -pivmin;
-                cnt += q < 0.f;
-            }
-            if (cnt <= k_asc) a = mid; else b = mid;
-            if (b - a <= 2.f * eps * fmaxf(fabsf(a), fabsf(b)) + pivmin) break;
         }
-        vals_desc[(long)z * n + i] = 0.5f * (a + b);
+        // new bracket: the largest point with count <= k and the smallest with count > k
+        const bool below = cnt <= k_asc;
+        const float na = row16_allmax(below && x > a ? x : a);
+        const float nb = -row16_allmax(-((!below && x < b) ? x : b));
+        const bool stalled = !(na > a) && !(nb < b);      // points collapsed onto the ends: resolution reached
+        a = na;
+        b = nb;
+        if (stalled || b - a <= 2.f * eps * fmaxf(fabsf(a), fabsf(b)) + pivmin) break;   // uniform within the row
     }
+    if (live && sub == 0) vals_desc[(long)z * n + i] = 0.5f * (a + b);
 }
 
 // ---------------------------------------------------------------------------
@@ -347,16 +362,22 @@ __global__ void __launch_bounds__(64) tridiag_invit_kernel(const float* __restri
             scale1 = scale2;
         }
     }
-    // inverse iteration: three solves with slagts-style pivot perturbation
-    for (int it = 0; it < 3; ++it) {
-        float nrm1 = 0.f;
-        for (int i = 0; i < n; ++i) nrm1 += fabsf(x[i * vpw]);
-        const float sc1 = (float)n * tnorm * eps / fmaxf(nrm1, 1e-37f);
-        // forward substitution (P L), scaling folded in
-        float prev = x[0] * sc1;
+    // inverse iteration: two solves with slagts-style pivot perturbation.  The shift is an eigenvalue to a few
+    // eps ||T||, so the first solve already amplifies the wanted direction by ~1/eps; the iterate enters each
+    // solve with unit 2-norm times n ||T|| eps (sstein's scaling), folded into the forward sweep.
+    const float s0 = (float)n * tnorm * eps;
+    {
+        float ss = 0.f;
+        for (int i = 0; i < n; ++i) ss = fmaf(x[i * vpw], x[i * vpw], ss);
+        const float sc = 1.f / sqrtf(fmaxf(ss, 1e-37f));
+        for (int i = 0; i < n; ++i) x[i * vpw] *= sc;
+    }
+    for (int it = 0; it < 2; ++it) {
+        // forward substitution (P L)
+        float prev = x[0] * s0;
         for (int i = 1; i < n; ++i) {
             const float ci = c[(i - 1) * vpw], flag = in[(i - 1) * vpw];
-            const float xi = x[i * vpw] * sc1;
+            const float xi = x[i * vpw] * s0;
             float keep, next;
             if (flag == 0.f) { keep = prev; next = xi - ci * prev; }
             else { keep = xi; next = prev - ci * xi; }
@@ -364,22 +385,19 @@ __global__ void __launch_bounds__(64) tridiag_invit_kernel(const float* __restri
             prev = next;
         }
         x[(n - 1) * vpw] = prev;
-        // back substitution (U)
-        float x1 = 0.f, x2 = 0.f, mx = 0.f;
+        // back substitution (U); |x| <= ~n here, so the squares cannot overflow
+        float x1 = 0.f, x2 = 0.f, ss = 0.f;
         for (int i = n - 1; i >= 0; --i) {
             float tmp = x[i * vpw] - b[i * vpw] * x1 - d2[i * vpw] * x2;    // b / d2 are 0 past the end
             float ak = a[i * vpw];
             if (fabsf(ak) < tol) ak = copysignf(tol, ak == 0.f ? 1.f : ak);
-            tmp /= ak;
+            tmp *= __builtin_amdgcn_rcpf(ak);
             x[i * vpw] = tmp;
-            mx = fmaxf(mx, fabsf(tmp));
+            ss = fmaf(tmp, tmp, ss);
             x2 = x1;
             x1 = tmp;
         }
-        const float inv = 1.f / fmaxf(mx, 1e-37f);
-        float ss = 0.f;
-        for (int i = 0; i < n; ++i) { const float u = x[i * vpw] * inv; ss = fmaf(u, u, ss); }
-        const float sc2 = inv / sqrtf(ss);
+        const float sc2 = 1.f / sqrtf(fmaxf(ss, 1e-37f));
         for (int i = 0; i < n; ++i) x[i * vpw] *= sc2;
     }
     float* out = Z + ((long)z * k + t) * n;
@@ -495,9 +513,7 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
 int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, float* vals_desc, hipStream_t stream) {
     BASD_CHECK_ARG(d && e && vals_desc && n > 0 && batch > 0);
     if (n > 8192) return BASD_EUNSUPPORTED;
-    int threads = ((n + 63) / 64) * 64;
-    if (threads > 1024) threads = 1024;
-    sturm_bisect_kernel<<<batch, threads, sizeof(float) * 2 * (size_t)n, stream>>>(d, e, n, vals_desc);
+    sturm_bisect_kernel<<<dim3((n + 63) / 64, batch), 1024, sizeof(float) * 2 * (size_t)n, stream>>>(d, e, n, vals_desc);
     BASD_RETURN_LAST();
 }
 
