@@ -106,6 +106,21 @@ def _align_token_count(tokens: torch.Tensor, target_n: int) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 # Procrustes loss over all extraction layers (autograd boundary)
 # --------------------------------------------------------------------------- #
+def _record_stream(obj, stream) -> None:
+    """Mark every tensor reachable from a (nested) state object as in use on `stream`."""
+    if isinstance(obj, torch.Tensor):
+        obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+    elif hasattr(obj, "__dataclass_fields__"):
+        for name in obj.__dataclass_fields__:
+            _record_stream(getattr(obj, name), stream)
+
+
 class _ProcrustesLayers(torch.autograd.Function):
     """(mix (E, L), has_cls, teachers, attns, *students) -> per-layer loss (E,)."""
 
@@ -512,8 +527,15 @@ class BASDLoss(nn.Module):
             tau = sel.temperatures.float()
             mix = torch.softmax(torch.zeros((len(students), 1), device=tau.device) / tau.unsqueeze(1), dim=1)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
-            with torch.cuda.stream(side):
-                sel._angles_from_spectra(spectra, keys)    # host reads the ranks; raises on rank 0 like the reference
+            # tail (eigenvectors, principal angles) on a third stream: the next step's eigen-solve chains do
+            # not queue behind it.  The host still reads the ranks here (and raises on rank 0 like the reference).
+            tail = self._selector_stream(main.device, 2)
+            tail.wait_stream(side)
+            tail.wait_stream(side2)
+            _record_stream(spectra, tail)
+            spectra["student_stream"] = None
+            with torch.cuda.stream(tail):
+                sel._angles_from_spectra(spectra, keys)
         else:
             mix = sel.mixing_weights(students, keys, teachers)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
