@@ -65,6 +65,25 @@ int basd_colmean_parts(int rows);
 int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_per_batch, long batch_stride,
                  int rows, int cols, int batch, int parts, float* partial, float* mean, hipStream_t stream);
 
+/* means[z][c] for a DEVICE table of n_mats same-layout matrices (one launch for all extraction layers of
+ * layer_selector.py:88-91).  `partial`: n_mats*parts*cols floats of scratch. */
+int basd_colmean_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long sd, int rows_per_batch, int rows,
+                       int cols, int n_mats, int parts, float* partial, float* means, hipStream_t stream);
+
+int basd_syrk_splits(int krows, int cols, int n_mats);
+
+/* out[z] (cols x cols, symmetric) = scales[z] * (X_z - 1 means[z]^T)^T (X_z - 1 means[z]^T),  z < n_mats.
+ * replaces the per-layer Gram matrices of the selector in one launch: `features.T @ features / M`
+ * layer_selector.py:13 (means row = 0, scale 1/M) and the centred z^T z behind the thin SVD :35-36, :90-92.
+ * Only lower-triangular 128x128 tiles are computed (half the operand traffic of basd_gemm_tn), then mirrored.
+ * x_ptrs: DEVICE array of base pointers; element (k, c) of X_z at x_ptrs[z] + (k / rows_per_batch)*sb +
+ * (k % rows_per_batch)*sn + c*sd.  means / scales (nullable): n_mats*cols / n_mats floats on the device.
+ * slabs: n_mats*splits*cols*cols floats of scratch (splits from basd_syrk_splits).  vec_ok: caller asserts
+ * every base pointer is 16-byte aligned. */
+int basd_syrk_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long sd, int rows_per_batch, int krows,
+                    int cols, int n_mats, const float* means, const float* scales, int splits, float* slabs,
+                    float* out, long out_stride, int vec_ok, hipStream_t stream);
+
 /* ---- one-sided Jacobi SVD / symmetric eigensolver ------------------------------------------ */
 
 int basd_jacobi_workspace_ints(int batch, int max_sweeps);

@@ -57,6 +57,33 @@ def test_gemm_tn_and_colmean(dev):
     assert _rel(out, a.double().transpose(1, 2) @ b.double()) < 2e-6
 
 
+@pytest.mark.parametrize("B,N,D,dtype", [(7, 197, 200, torch.float32), (9, 50, 384, torch.float32),
+                                         (33, 17, 130, torch.bfloat16), (3, 40, 64, torch.float32)])
+def test_centered_grams_multi(dev, B, N, D, dtype):
+    """basd_syrk_multi + basd_colmean_multi: symmetric tile pairs, pointer table, per-matrix mean / scale."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(B * N + D)
+    xs = [((torch.randn(B, N, D, generator=g) * (1 + 0.3 * i) + 0.7 * i).to(dtype).to(dev))[:, 1:, :] for i in range(3)]
+    M = B * (N - 1)
+    out, means = ops.centered_grams(xs, centered=[True, False, True], scales=[1.0, 1.0 / M, 0.5])
+    tol = 5e-6 if dtype == torch.float32 else 2e-5
+    for i, x in enumerate(xs):
+        flat = x.double().reshape(-1, D)
+        mu = flat.mean(0)
+        assert _rel(means[i], mu) < 1e-6
+        c = flat - (mu.float().double() if i != 1 else 0.0)
+        ref = c.T @ c * (1.0, 1.0 / M, 0.5)[i]
+        assert _rel(out[i], ref) < tol, (i, float(_rel(out[i], ref)))
+        assert torch.equal(out[i], out[i].T), "mirrored tiles must be bit-identical"
+    # default: every matrix centred, unit scale, 2-D operands
+    flat = [x.reshape(-1, D).contiguous() for x in xs[:2]]
+    out2, _ = ops.centered_grams(flat)
+    for i in range(2):
+        d = flat[i].double()
+        c = d - d.mean(0).float().double()
+        assert _rel(out2[i], c.T @ c) < tol
+
+
 @pytest.mark.parametrize("n,rows_dot,rows_tot", [(49, 49, 98), (50, 50, 100), (7, 7, 7), (96, 96, 192), (130, 130, 130)])
 def test_jacobi_lds_invariants(dev, n, rows_dot, rows_tot):
     from basd_amd import ops

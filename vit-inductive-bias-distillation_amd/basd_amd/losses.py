@@ -231,30 +231,38 @@ class GrassmannianLayerSelector(nn.Module):
 
     # ---- teacher side: ranks + subspaces -------------------------------------------------
     @torch.no_grad()
-    def _teacher_grams(self, teachers: list[torch.Tensor]):
+    def _teacher_projection(self, t: torch.Tensor) -> torch.Tensor:
+        return ops.gemm_nt(ops.as_supported(t), self.proj_t.float().contiguous())   # (M, d_s)  layer_selector.py:72 / :135
+
+    def _teacher_grams(self, teachers: list[torch.Tensor], projected: list[torch.Tensor] | None = None):
         """Per teacher layer: projected tokens -> uncentred Gram / M (for the MP rank, layer_selector.py:12-15)
-        and centred Gram (for the subspace, :35)."""
+        and centred Gram (for the subspace, :35).  ``projected``: projections already queued by the caller."""
         d_s = self.student_dim
         L = len(teachers)
         B, n_t, _ = teachers[0].shape
         M = B * n_t
         proj_t = self.proj_t.float().contiguous()
         n_u = d_s if M >= d_s else M
+        zs = [projected[l] if projected is not None else self._teacher_projection(t)
+              for l, t in enumerate(teachers)]
+        if n_u == d_s:
+            # uncentred / M and centred Grams of every layer's projected tokens: one symmetric launch,
+            # laid out [uncentred 0..L-1, centred 0..L-1]
+            stack, _ = ops.centered_grams(zs + zs, centered=[False] * L + [True] * L,
+                                          scales=[1.0 / M] * L + [1.0] * L)
+            return stack[:L], stack[L:], M, stack
         g_u = torch.empty((L, n_u, n_u), device=proj_t.device, dtype=torch.float32)
-        g_c = torch.empty((L, d_s, d_s), device=proj_t.device, dtype=torch.float32)
-        for l, t in enumerate(teachers):
-            z = ops.gemm_nt(ops.as_supported(t), proj_t)              # (M, d_s)  layer_selector.py:72 / :135
+        for l, z in enumerate(zs):
             g_u[l] = _uncentred_gram(z)
-            mean = ops.colmean(z)
-            g_c[l] = ops.gemm_tn(z, z, mean_a=mean, mean_b=mean)
-        return g_u, g_c, M
+        g_c, _ = ops.centered_grams(zs)
+        return g_u, g_c, M, None
 
     @torch.no_grad()
     def _estimate_ranks(self, all_teacher_tokens: dict[int, torch.Tensor]) -> None:
         keys = list(all_teacher_tokens.keys())
         teachers = ops._check_common_layout([ops.as_supported(all_teacher_tokens[k]) for k in keys],
                                             "teacher token tensors")
-        g_u, _, M = self._teacher_grams(teachers)
+        g_u, _, M, _ = self._teacher_grams(teachers)
         vals_u = _eigenvalues_desc(g_u)
         ranks_dev = ops.mp_rank_device(vals_u, M, self.student_dim, cap=self.student_dim - 1)   # :74
         for k, r in zip(keys, ranks_dev.tolist()):
@@ -282,18 +290,17 @@ class GrassmannianLayerSelector(nn.Module):
 
         # ---- student side: centred Grams -> eigen-solve ----
         cur = torch.cuda.current_stream()
+        projected = None
         if student_stream is not None:
             student_stream.wait_stream(cur)
+            # two chains: give the teacher stream its first (large) launch before the host queues the
+            # student chain, so both start together
+            projected = [self._teacher_projection(t) for t in teachers]
         with torch.cuda.stream(student_stream if student_stream is not None else cur):
-            s_stack = torch.empty((E, d_s, d_s), device=dev, dtype=torch.float32)
-            means = []
-            for e, x in enumerate(students):
-                x = ops.as_supported(x)
-                mean = ops.colmean(x)
-                means.append(mean)
-                # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
-                # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
-                s_stack[e] = ops.gemm_tn(x, x, mean_a=mean, mean_b=mean)
+            # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
+            # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
+            xs = ops._check_common_layout([ops.as_supported(x) for x in students], "student token tensors")
+            s_stack, means = ops.centered_grams(xs)
             st["means"] = means
             if stud_jacobi:
                 st["s_stack"], st["s_colnorm"] = s_stack, ops.jacobi_onesided(s_stack, d_s)
@@ -301,13 +308,11 @@ class GrassmannianLayerSelector(nn.Module):
                 st["s_ts"] = ops.tridiag_eigenvalues(s_stack)
 
         # ---- teacher side: projection, Grams, eigen-solve, MP ranks ----
-        g_u, g_c, M = self._teacher_grams(teachers)
-        same = g_u.shape[1] == d_s
+        g_u, g_c, M, t_stack = self._teacher_grams(teachers, projected)
+        same = t_stack is not None
         o_c = L if same else 0
-        t_stack = torch.empty((o_c + L, d_s, d_s), device=dev, dtype=torch.float32)
-        if same:
-            t_stack[:L] = g_u
-        t_stack[o_c:] = g_c
+        if not same:
+            t_stack = g_c
         st["o_c"] = o_c
         if tri:
             ts = ops.tridiag_eigenvalues(t_stack)
@@ -527,16 +532,20 @@ class BASDLoss(nn.Module):
             tau = sel.temperatures.float()
             mix = torch.softmax(torch.zeros((len(students), 1), device=tau.device) / tau.unsqueeze(1), dim=1)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
-            # tail (eigenvectors, principal angles) on a third stream: the next step's eigen-solve chains do
-            # not queue behind it.  The host still reads the ranks here (and raises on rank 0 like the reference).
-            tail = self._selector_stream(main.device, 2)
-            tail.wait_stream(side)
-            tail.wait_stream(side2)
-            _record_stream(spectra, tail)
-            spectra["student_stream"] = None
-            with torch.cuda.stream(tail):
-                sel._angles_from_spectra(spectra, keys)
+
+            def selector_tail():
+                # eigenvectors + principal angles on a third stream: the next step's eigen-solve chains do not
+                # queue behind it.  The host reads the ranks here (and raises on rank 0 like the reference);
+                # called last so that everything else of the step is queued before the host blocks.
+                tail = self._selector_stream(main.device, 2)
+                tail.wait_stream(side)
+                tail.wait_stream(side2)
+                _record_stream(spectra, tail)
+                spectra["student_stream"] = None
+                with torch.cuda.stream(tail):
+                    sel._angles_from_spectra(spectra, keys)
         else:
+            selector_tail = None
             mix = sel.mixing_weights(students, keys, teachers)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
         geo_loss = geo_layers.mean()
@@ -547,4 +556,7 @@ class BASDLoss(nn.Module):
         inv = torch.stack([1.0 / v.detach().clamp(min=eps) for v in vals])
         w = inv / inv.sum()
         self.last_components = {"ce": ce_loss.detach(), "geo_layers": geo_layers.detach(), "mix": mix.detach()}
-        return sum(w[i] * vals[i] for i in range(len(vals)))
+        total = sum(w[i] * vals[i] for i in range(len(vals)))
+        if selector_tail is not None:
+            selector_tail()
+        return total

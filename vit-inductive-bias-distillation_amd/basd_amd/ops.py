@@ -115,6 +115,45 @@ def colmean(x: torch.Tensor) -> torch.Tensor:
     return mean
 
 
+def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None,
+                   scales: list[float] | None = None, out: torch.Tensor | None = None
+                   ) -> tuple[torch.Tensor, torch.Tensor]:
+    """Gram matrices of same-layout (B,N,D) / (M,D) views in two launches (+ reductions):
+    out[z] = scales[z] * (X_z - 1 mu_z^T)^T (X_z - 1 mu_z^T), mu_z the column means (0 where not centred).
+    Returns (out (n, D, D), means (n, D))."""
+    _require_cuda(*xs)
+    n = len(xs)
+    ptr, dt, sb, sn, sd, rpb = _tok3(xs[0])
+    for x in xs[1:]:
+        assert _tok3(x)[1:] == (dt, sb, sn, sd, rpb) and x.shape == xs[0].shape, "Gram operands must share a layout"
+    dev = xs[0].device
+    rows = xs[0].shape[0] * xs[0].shape[1] if xs[0].dim() == 3 else xs[0].shape[0]
+    cols = xs[0].shape[-1]
+    table = _ptr_table(xs)
+    means = torch.empty((n, cols), device=dev, dtype=torch.float32)
+    parts = _lib.query("basd_colmean_parts", rows)
+    partial = torch.empty((n, parts, cols), device=dev, dtype=torch.float32)
+    _lib.call("basd_colmean_multi", table.data_ptr(), dt, sb, sn, sd, rpb, rows, cols, n, parts, partial.data_ptr(),
+              means.data_ptr(), _stream())
+    if centered is not None and not all(centered):
+        keep = _device_consts(tuple(1.0 if c else 0.0 for c in centered), torch.float32, dev)
+        means_used = means * keep.unsqueeze(1)
+    else:
+        means_used = means
+    sc = None
+    if scales is not None:
+        sc = _device_consts(tuple(float(s) for s in scales), torch.float32, dev)
+    splits = _lib.query("basd_syrk_splits", rows, cols, n)
+    slabs = torch.empty((n * splits, cols, cols), device=dev, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((n, cols, cols), device=dev, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.shape == (n, cols, cols) and out[0].is_contiguous()
+    vec_ok = int(all(x.data_ptr() % 16 == 0 for x in xs))
+    _lib.call("basd_syrk_multi", table.data_ptr(), dt, sb, sn, sd, rpb, rows, cols, n, means_used.data_ptr(),
+              _ptr(sc), splits, slabs.data_ptr(), out.data_ptr(), out.stride(0), vec_ok, _stream())
+    return out, means
+
+
 # --------------------------------------------------------------------------- #
 # Jacobi solver
 # --------------------------------------------------------------------------- #
@@ -264,8 +303,23 @@ def taps(n_in: int, n_out: int, device: torch.device) -> Taps | None:
 
 def _ptr_table(tensors: list[torch.Tensor]) -> torch.Tensor:
     """Device array of base pointers (K8 of SURVEY.md: a pointer table instead of torch.stack)."""
-    host = torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64)
-    return host.to(tensors[0].device, non_blocking=True)
+    return _device_consts(tuple(t.data_ptr() for t in tensors), torch.int64, tensors[0].device)
+
+
+_CONSTS: dict = {}
+
+
+def _device_consts(values: tuple, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """Small read-only device arrays (pointer tables, per-matrix scales), cached by value: the caching
+    allocator hands the same addresses back every step, so the steady state uploads nothing."""
+    key = (values, dtype, device)
+    t = _CONSTS.get(key)
+    if t is None:
+        if len(_CONSTS) > 512:
+            _CONSTS.clear()
+        t = torch.tensor(values, dtype=dtype).to(device)
+        _CONSTS[key] = t
+    return t
 
 
 # --------------------------------------------------------------------------- #

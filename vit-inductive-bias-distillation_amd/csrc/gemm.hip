@@ -303,6 +303,105 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmOperand A, GemmOperand
     store_tile(C, ldc, M, N, m0, n0, acc, wm, wn, lane, scale);
 }
 
+
+// ---------------------------------------------------------------------------
+// Multi-matrix symmetric TN (centred Gram / SYRK):  G[z] = scale[z] * (X_z - 1 mean_z^T)^T (X_z - 1 mean_z^T)
+//   grid = (T(T+1)/2 lower-triangular 128x128 tile pairs, splits, n_mats), block = 256.
+//   X_z share shape and strides, base pointers come from a device table.  Only tiles (mi >= ni) are
+//   computed; a diagonal tile stages its column slab once and feeds both MFMA operands from it.  Half the
+//   column-slab traffic of the general TN kernel (9 instead of 18 slab reads at 384 columns).
+//   syrk_reduce_kernel folds the split slabs in fixed order and mirrors the strict lower tiles.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void tri_tile(int p, int& mi, int& ni) {
+    mi = 0;
+    while ((mi + 1) * (mi + 2) / 2 <= p) ++mi;
+    ni = p - mi * (mi + 1) / 2;
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) syrk_tn_kernel(const void* const* __restrict__ ptrs, GemmOperand X, int cols,
+                                                      int Krows, int splits, const float* __restrict__ means,
+                                                      float* __restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * TN_BK * 128];
+    int tmi, tni;
+    tri_tile(blockIdx.x, tmi, tni);
+    const bool diag = tmi == tni;
+    float* tA = lds;
+    float* tB = diag ? lds : lds + TN_BK * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = tmi * BM, n0 = tni * BN;
+    const int z = blockIdx.z, sp = blockIdx.y;
+    X.ptr = ptrs[z];
+    const float* mean = means ? means + (long)z * cols : nullptr;
+    float* C = slabs + ((long)z * splits + sp) * (long)cols * cols;
+    const int chunks = (Krows + TN_BK - 1) / TN_BK;
+    const int per = (chunks + splits - 1) / splits;
+    const int k_begin = sp * per * TN_BK;
+    int k_end = k_begin + per * TN_BK;
+    if (k_end > Krows) k_end = Krows;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool is_b = tid >= 128;
+    const bool loader = !(is_b && diag);       // wave-uniform
+    const int t = tid & 127;
+    const int col0 = is_b ? n0 : m0;
+    float* tile = is_b ? tB : tA;
+    float reg[2][4][4];
+    if (loader && k_begin < k_end) tn_load<T, VEC>(X, k_end, cols, k_begin, col0, t, mean, reg);
+    const int i = lane & 31, h = lane >> 5;
+    for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
+        __syncthreads();
+        if (loader) tn_store_lds(tile, t, reg);
+        __syncthreads();
+        if (loader && k0 + TN_BK < k_end) tn_load<T, VEC>(X, k_end, cols, k0 + TN_BK, col0, t, mean, reg);
+#pragma unroll
+        for (int g = 0; g < TN_BK / 8; ++g) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const float4*)(tA + (((2 * g + h) * 128 + wm * 64 + mi * 32 + i) << 2));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *(const float4*)(tB + (((2 * g + h) * 128 + wn * 64 + ni * 32 + i) << 2));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+    }
+    store_tile(C, cols, cols, cols, m0, n0, acc, wm, wn, lane, 1.f);
+}
+
+// grid = (tile pairs * 64, n_mats), block 256: one element of a lower tile per thread.
+__global__ void __launch_bounds__(256) syrk_reduce_kernel(const float* __restrict__ slabs, int cols, int splits,
+                                                          const float* __restrict__ scales, float* __restrict__ out,
+                                                          long out_stride) {
+    int tmi, tni;
+    tri_tile(blockIdx.x >> 6, tmi, tni);
+    const int e = (blockIdx.x & 63) * 256 + threadIdx.x;
+    const int r = tmi * BM + (e >> 7), c = tni * BN + (e & 127);
+    if (r >= cols || c >= cols) return;
+    const int z = blockIdx.y;
+    const long mat = (long)cols * cols;
+    const float* in = slabs + (long)z * splits * mat + (long)r * cols + c;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += in[k * mat];
+    s *= scales ? scales[z] : 1.f;
+    float* o = out + (long)z * out_stride;
+    o[(long)r * cols + c] = s;
+    if (tmi != tni) o[(long)c * cols + r] = s;
+}
+
 // out[i] = scale * sum_s slabs[s][i]   (fixed order: deterministic)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, long slab_stride, int splits, long count,
                                     float scale, float* __restrict__ out, long batch_in_stride,
@@ -320,11 +419,12 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, long slab_s
 //   stage 1: grid = (ceil(cols/256), parts, batch) partial sums; stage 2 folds the parts.
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_partial_kernel(GemmOperand X, int rows, int cols, int parts,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial,
+                                                             const void* const* __restrict__ ptrs = nullptr) {
     // block = 64 columns x 4 row groups; grid = (ceil(cols/64), parts, batch)
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-    const T* base = (const T*)X.ptr + (long)blockIdx.z * X.batch_stride;
+    const T* base = ptrs ? (const T*)ptrs[blockIdx.z] : (const T*)X.ptr + (long)blockIdx.z * X.batch_stride;
     const int per = (rows + parts - 1) / parts;
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     float s = 0.f;
@@ -447,6 +547,57 @@ int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_p
     else if (dtype == BASD_DTYPE_BF16) colsum_partial_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial);
     else return BASD_EINVAL;
     colsum_final_kernel<<<dim3((cols + 63) / 64, batch), 256, 0, stream>>>(partial, cols, parts, 1.f / rows, mean);
+    BASD_RETURN_LAST();
+}
+
+int basd_syrk_splits(int krows, int cols, int n_mats) {
+    const int tiles = (cols + BM - 1) / BM, pairs = tiles * (tiles + 1) / 2;
+    int s = (1024 + pairs * n_mats - 1) / (pairs * n_mats);
+    const int cap = krows / 64;
+    if (s > cap) s = cap;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return s;
+}
+
+// out[z] (cols x cols, symmetric) = scales[z] * (X_z - 1 means[z]^T)^T (X_z - 1 means[z]^T),  z < n_mats.
+//   x_ptrs: DEVICE array of n_mats base pointers; all X_z share dtype, shape (krows x cols) and strides
+//   (element (k, c) at x_ptrs[z] + (k / rows_per_batch)*sb + (k % rows_per_batch)*sn + c*sd).
+//   means (nullable): n_mats*cols floats;  scales (nullable): n_mats floats, both on the device.
+//   slabs: n_mats*splits*cols*cols floats of scratch, splits from basd_syrk_splits.
+int basd_syrk_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long sd, int rows_per_batch, int krows,
+                    int cols, int n_mats, const float* means, const float* scales, int splits, float* slabs,
+                    float* out, long out_stride, int vec_ok, hipStream_t stream) {
+    BASD_CHECK_ARG(x_ptrs && slabs && out && krows > 0 && cols > 0 && n_mats > 0 && splits >= 1 && rows_per_batch > 0);
+    BASD_CHECK_ARG(out_stride >= (long)cols * cols);
+    GemmOperand X{nullptr, sb, sn, sd, rows_per_batch, 0};
+    const int tiles = (cols + BM - 1) / BM, pairs = tiles * (tiles + 1) / 2;
+    const dim3 grid(pairs, splits, n_mats);
+    if (dtype == BASD_DTYPE_F32) {
+        const bool vec = vec_ok && sd == 1 && sb % 4 == 0 && sn % 4 == 0;
+        if (vec) syrk_tn_kernel<float, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, means, slabs);
+        else syrk_tn_kernel<float, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, means, slabs);
+    } else if (dtype == BASD_DTYPE_BF16) {
+        if (sd == 1) syrk_tn_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, means, slabs);
+        else syrk_tn_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, means, slabs);
+    } else {
+        return BASD_EINVAL;
+    }
+    syrk_reduce_kernel<<<dim3(pairs * 64, n_mats), 256, 0, stream>>>(slabs, cols, splits, scales, out, out_stride);
+    BASD_RETURN_LAST();
+}
+
+// means[z][c] = (1/rows) sum_r X_z(r, c) for a device table of same-layout matrices.
+//   partial: n_mats*parts*cols floats of scratch (parts from basd_colmean_parts).
+int basd_colmean_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long sd, int rows_per_batch, int rows,
+                       int cols, int n_mats, int parts, float* partial, float* means, hipStream_t stream) {
+    BASD_CHECK_ARG(x_ptrs && partial && means && rows > 0 && cols > 0 && n_mats > 0 && parts >= 1);
+    GemmOperand X{nullptr, sb, sn, sd, rows_per_batch, 0};
+    const dim3 grid((cols + 63) / 64, parts, n_mats);
+    if (dtype == BASD_DTYPE_F32) colsum_partial_kernel<float><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial, x_ptrs);
+    else if (dtype == BASD_DTYPE_BF16) colsum_partial_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial, x_ptrs);
+    else return BASD_EINVAL;
+    colsum_final_kernel<<<dim3((cols + 63) / 64, n_mats), 256, 0, stream>>>(partial, cols, parts, 1.f / rows, means);
     BASD_RETURN_LAST();
 }
 
