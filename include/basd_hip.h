@@ -66,9 +66,11 @@ int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_p
                  int rows, int cols, int batch, int parts, float* partial, float* mean, hipStream_t stream);
 
 /* means[z][c] for a DEVICE table of n_mats same-layout matrices (one launch for all extraction layers of
- * layer_selector.py:88-91).  `partial`: n_mats*parts*cols floats of scratch. */
+ * layer_selector.py:88-91).  `partial`: n_mats*parts*cols floats of scratch.  vec_ok: caller asserts every base
+ * pointer is 16-byte aligned. */
 int basd_colmean_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long sd, int rows_per_batch, int rows,
-                       int cols, int n_mats, int parts, float* partial, float* means, hipStream_t stream);
+                       int cols, int n_mats, int parts, float* partial, float* means, int vec_ok,
+                       hipStream_t stream);
 
 int basd_syrk_splits(int krows, int cols, int n_mats);
 

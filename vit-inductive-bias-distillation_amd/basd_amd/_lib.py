@@ -23,7 +23,7 @@ SIGNATURES = {
                      vp, i64, i64, f32, vp],
     "basd_colmean_parts": [i32],
     "basd_colmean": [vp, i32, i64, i64, i64, i32, i64, i32, i32, i32, i32, vp, vp, vp],
-    "basd_colmean_multi": [vp, i32, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, vp],
+    "basd_colmean_multi": [vp, i32, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp],
     "basd_syrk_splits": [i32, i32, i32],
     "basd_syrk_multi": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, i32, vp, vp, i64, i32, vp],
     "basd_jacobi_workspace_ints": [i32, i32],

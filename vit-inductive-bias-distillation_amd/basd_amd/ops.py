@@ -116,8 +116,8 @@ def colmean(x: torch.Tensor) -> torch.Tensor:
 
 
 def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None,
-                   scales: list[float] | None = None, out: torch.Tensor | None = None
-                   ) -> tuple[torch.Tensor, torch.Tensor]:
+                   scales: list[float] | None = None, out: torch.Tensor | None = None,
+                   splits: int | None = None) -> tuple[torch.Tensor, torch.Tensor]:
     """Gram matrices of same-layout (B,N,D) / (M,D) views in two launches (+ reductions):
     out[z] = scales[z] * (X_z - 1 mu_z^T)^T (X_z - 1 mu_z^T), mu_z the column means (0 where not centred).
     Returns (out (n, D, D), means (n, D))."""
@@ -133,8 +133,9 @@ def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None
     means = torch.empty((n, cols), device=dev, dtype=torch.float32)
     parts = _lib.query("basd_colmean_parts", rows)
     partial = torch.empty((n, parts, cols), device=dev, dtype=torch.float32)
+    vec_ok = int(all(x.data_ptr() % 16 == 0 for x in xs))
     _lib.call("basd_colmean_multi", table.data_ptr(), dt, sb, sn, sd, rpb, rows, cols, n, parts, partial.data_ptr(),
-              means.data_ptr(), _stream())
+              means.data_ptr(), vec_ok, _stream())
     if centered is not None and not all(centered):
         keep = _device_consts(tuple(1.0 if c else 0.0 for c in centered), torch.float32, dev)
         means_used = means * keep.unsqueeze(1)
@@ -143,12 +144,12 @@ def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None
     sc = None
     if scales is not None:
         sc = _device_consts(tuple(float(s) for s in scales), torch.float32, dev)
-    splits = _lib.query("basd_syrk_splits", rows, cols, n)
+    if splits is None:
+        splits = _lib.query("basd_syrk_splits", rows, cols, n)
     slabs = torch.empty((n * splits, cols, cols), device=dev, dtype=torch.float32)
     if out is None:
         out = torch.empty((n, cols, cols), device=dev, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.shape == (n, cols, cols) and out[0].is_contiguous()
-    vec_ok = int(all(x.data_ptr() % 16 == 0 for x in xs))
     _lib.call("basd_syrk_multi", table.data_ptr(), dt, sb, sn, sd, rpb, rows, cols, n, means_used.data_ptr(),
               _ptr(sc), splits, slabs.data_ptr(), out.data_ptr(), out.stride(0), vec_ok, _stream())
     return out, means

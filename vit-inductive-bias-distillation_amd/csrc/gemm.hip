@@ -66,17 +66,38 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int 
 // ---------------------------------------------------------------------------
 constexpr int NT_BK = 32, NT_LD = 36;
 
-template <typename TA, bool VEC>
-__device__ __forceinline__ void nt_load(const GemmOperand& o, int rows_total, int K, int row0, int k0, int tid,
-                                        float (&reg)[4][4]) {
-    const TA* base = (const TA*)o.ptr;
+// Row offsets are fixed for the whole K loop: computed once (rows past the end clamp to the last row; their
+// products land in output rows that store_tile never writes).  The interior K loop is branch-free so that
+// all of a thread's loads are in flight together; only a ragged last chunk takes the predicated form.
+template <bool VEC>
+__device__ __forceinline__ void nt_rows(const GemmOperand& o, int rows_total, int row0, int tid, long (&off)[4]) {
     if (VEC) {
         // lane -> (row, 4 consecutive k): 8 lanes cover one 128-byte row segment
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int f = tid + 256 * j, row = row0 + (f >> 3), k = k0 + (f & 7) * 4;
-            if (row < rows_total && k + 3 < K) {
-                const TA* p = base + row_off(o, row) + (long)k * o.sd;
+            int row = row0 + (tid >> 3) + 32 * j;
+            if (row >= rows_total) row = rows_total - 1;
+            off[j] = row_off(o, row) + (long)((tid & 7) * 4) * o.sd;
+        }
+    } else {
+        // lanes along rows (row-contiguous / generic layouts): one row per thread, k = k0 + (tid >> 7) + 2 q
+        int row = row0 + (tid & 127);
+        if (row >= rows_total) row = rows_total - 1;
+        off[0] = row_off(o, row) + (long)(tid >> 7) * o.sd;
+        off[1] = off[2] = off[3] = 0;
+    }
+}
+
+template <typename TA, bool VEC>
+__device__ __forceinline__ void nt_load(const GemmOperand& o, const long (&off)[4], int K, int k0, int tid,
+                                        float (&reg)[4][4]) {
+    const TA* base = (const TA*)o.ptr;
+    const bool full = k0 + NT_BK <= K;     // uniform
+    if (VEC) {
+        if (full) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const TA* p = base + off[j] + k0;
                 if (sizeof(TA) == 4) {
                     const float4 v = *(const float4*)p;
                     reg[j][0] = v.x; reg[j][1] = v.y; reg[j][2] = v.z; reg[j][3] = v.w;
@@ -84,23 +105,24 @@ __device__ __forceinline__ void nt_load(const GemmOperand& o, int rows_total, in
 #pragma unroll
                     for (int c = 0; c < 4; ++c) reg[j][c] = to_f32(p[c]);
                 }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int kk = k + c;
-                    reg[j][c] = (row < rows_total && kk < K) ? to_f32(base[row_off(o, row) + (long)kk * o.sd]) : 0.f;
-                }
             }
+        } else {
+            const int k = k0 + (tid & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) reg[j][c] = (k + c < K) ? to_f32(base[off[j] + k0 + c]) : 0.f;
         }
     } else {
-        // lanes along rows (row-contiguous / generic layouts): f -> (k = f / 128, row = f % 128)
+        const TA* p = base + off[0] + (long)k0 * o.sd;
+        if (full) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int q = 0; q < 16; ++q) reg[q >> 2][q & 3] = to_f32(p[(long)(2 * q) * o.sd]);
+        } else {
+            const int k = k0 + (tid >> 7);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int f = tid + 256 * (j * 4 + c), row = row0 + (f & 127), k = k0 + (f >> 7);
-                reg[j][c] = (row < rows_total && k < K) ? to_f32(base[row_off(o, row) + (long)k * o.sd]) : 0.f;
-            }
+            for (int q = 0; q < 16; ++q) reg[q >> 2][q & 3] = (k + 2 * q < K) ? to_f32(p[(long)(2 * q) * o.sd]) : 0.f;
+        }
     }
 }
 
@@ -145,8 +167,11 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float ra[4][4], rb[4][4];
-    nt_load<TA, VEC_A>(A, M, K, m0, 0, tid, ra);
-    nt_load<float, true>(B, N, K, n0, 0, tid, rb);
+    long offa[4], offb[4];
+    nt_rows<VEC_A>(A, M, m0, tid, offa);
+    nt_rows<true>(B, N, n0, tid, offb);
+    nt_load<TA, VEC_A>(A, offa, K, 0, tid, ra);
+    nt_load<float, true>(B, offb, K, 0, tid, rb);
     const int i = lane & 31, h = lane >> 5;
     for (int k0 = 0; k0 < K; k0 += NT_BK) {
         __syncthreads();
@@ -154,8 +179,8 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand
         nt_store_lds<true>(tB, tid, rb);
         __syncthreads();
         if (k0 + NT_BK < K) {
-            nt_load<TA, VEC_A>(A, M, K, m0, k0 + NT_BK, tid, ra);
-            nt_load<float, true>(B, N, K, n0, k0 + NT_BK, tid, rb);
+            nt_load<TA, VEC_A>(A, offa, K, k0 + NT_BK, tid, ra);
+            nt_load<float, true>(B, offb, K, k0 + NT_BK, tid, rb);
         }
 #pragma unroll
         for (int g = 0; g < NT_BK / 8; ++g) {
@@ -188,53 +213,99 @@ constexpr int TN_BK = 32;
 // Stage a (TN_BK rows x 128 columns) slab as [k/4][column][4]: one ds_read_b128 then yields the four
 // k-steps of a lane (lane half h takes k-group 2g + h; same permutation for A and B).  Threads 0..127 stage
 // A, 128..255 stage B; each thread transposes two 4x4 blocks in registers.
+// A thread stages 8 rows (2 groups of 4 consecutive k) x 4 consecutive columns.  TnCursor carries the
+// element offset and the in-batch row index of each of its rows and advances by TN_BK rows per chunk with
+// no division; interior chunks of interior column tiles load branch-free (all 8 loads in flight together),
+// ragged chunks / tiles take the predicated form.  The mean is subtracted while staging into LDS (not at
+// load time, which would put a wait on the loads ahead of the MFMA block); rows past the end are filled
+// with the mean so that they stage as exact zeros.
+struct TnCursor {
+    long off[2];   // element offset of the first row of each 4-row group
+    int n[2];      // its row index inside the batch item
+};
+
+__device__ __forceinline__ void tn_cursor_init(TnCursor& cu, const GemmOperand& o, int k_begin, int t) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k_begin + ((t >> 5) + 4 * j) * 4;
+        const int b = k / o.rows_per_batch, n = k - b * o.rows_per_batch;
+        cu.n[j] = n;
+        cu.off[j] = (long)b * o.sb + (long)n * o.sn;
+    }
+}
+
+__device__ __forceinline__ void tn_cursor_advance(TnCursor& cu, const GemmOperand& o) {
+    const long wrap = o.sb - (long)o.rows_per_batch * o.sn;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        cu.n[j] += TN_BK;
+        cu.off[j] += (long)TN_BK * o.sn;
+        while (cu.n[j] >= o.rows_per_batch) { cu.n[j] -= o.rows_per_batch; cu.off[j] += wrap; }
+    }
+}
+
+// offset of row r (0..3) of group j: the group may straddle a batch-item boundary
+__device__ __forceinline__ long tn_row(const TnCursor& cu, const GemmOperand& o, int j, int r) {
+    int n = cu.n[j] + r;
+    long off = cu.off[j] + (long)r * o.sn;
+    const long wrap = o.sb - (long)o.rows_per_batch * o.sn;
+    while (n >= o.rows_per_batch) { n -= o.rows_per_batch; off += wrap; }
+    return off;
+}
+
+// mean4: the thread's four column means (0 when not centred / column out of range)
+__device__ __forceinline__ void tn_mean4(const float* __restrict__ mean, int cols, int col0, int t, float (&m4)[4]) {
+    const int c = col0 + (t & 31) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m4[e] = (mean && c + e < cols) ? mean[c + e] : 0.f;
+}
+
 template <typename T, bool VEC>
-__device__ __forceinline__ void tn_load(const GemmOperand& o, int krows_end, int cols, int k0, int col0, int t,
-                                        const float* __restrict__ mean, float (&reg)[2][4][4]) {
+__device__ __forceinline__ void tn_load(const GemmOperand& o, const TnCursor& cu, int krows_end, int cols, int k0,
+                                        int col0, int t, const float (&m4)[4], float (&reg)[2][4][4]) {
     const T* base = (const T*)o.ptr;
     const int c = col0 + (t & 31) * 4;
+    if (VEC && k0 + TN_BK <= krows_end && col0 + 128 <= cols) {      // uniform
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const T* p = base + tn_row(cu, o, j, r) + c;
+                if (sizeof(T) == 4) {
+                    const float4 v = *(const float4*)p;
+                    reg[j][r][0] = v.x; reg[j][r][1] = v.y; reg[j][r][2] = v.z; reg[j][r][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) reg[j][r][e] = to_f32(p[e]);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int kg = (t >> 5) + 4 * j;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int k = k0 + kg * 4 + r;
-            if (k < krows_end) {
-                const T* p = base + row_off(o, k);
-                if (VEC && c + 3 < cols) {
-                    if (sizeof(T) == 4) {
-                        const float4 v = *(const float4*)(p + c);
-                        reg[j][r][0] = v.x; reg[j][r][1] = v.y; reg[j][r][2] = v.z; reg[j][r][3] = v.w;
-                    } else {
+            const bool row_ok = k0 + kg * 4 + r < krows_end;
+            const long ro = row_ok ? tn_row(cu, o, j, r) : 0;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) reg[j][r][e] = to_f32(p[c + e]);
-                    }
-                    if (mean) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) reg[j][r][e] -= mean[c + e];
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int cc = c + e;
-                        reg[j][r][e] = cc < cols ? to_f32(p[(long)cc * o.sd]) - (mean ? mean[cc] : 0.f) : 0.f;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) reg[j][r][e] = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const int cc = c + e;
+                reg[j][r][e] = !row_ok ? m4[e] : (cc < cols ? to_f32(base[ro + (long)cc * o.sd]) : 0.f);
             }
         }
     }
 }
 
-__device__ __forceinline__ void tn_store_lds(float* __restrict__ tile, int t, const float (&reg)[2][4][4]) {
+__device__ __forceinline__ void tn_store_lds(float* __restrict__ tile, int t, const float (&reg)[2][4][4],
+                                             const float (&m4)[4]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int kg = (t >> 5) + 4 * j, m = (t & 31) * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            *(float4*)(tile + ((kg * 128 + m + e) << 2)) = make_float4(reg[j][0][e], reg[j][1][e], reg[j][2][e], reg[j][3][e]);
+            *(float4*)(tile + ((kg * 128 + m + e) << 2)) =
+                make_float4(reg[j][0][e] - m4[e], reg[j][1][e] - m4[e], reg[j][2][e] - m4[e], reg[j][3][e] - m4[e]);
     }
 }
 
@@ -274,14 +345,20 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmOperand A, GemmOperand
     const int cols = is_b ? N : M, col0 = is_b ? n0 : m0;
     const float* mean = is_b ? mean_b : mean_a;
     float* tile = is_b ? tB : tA;
-    float reg[2][4][4];
-    if (k_begin < k_end) tn_load<T, VEC>(op, k_end, cols, k_begin, col0, t, mean, reg);
+    float reg[2][4][4], m4[4];
+    TnCursor cu;
+    tn_cursor_init(cu, op, k_begin, t);
+    tn_mean4(mean, cols, col0, t, m4);
+    if (k_begin < k_end) tn_load<T, VEC>(op, cu, k_end, cols, k_begin, col0, t, m4, reg);
     const int i = lane & 31, h = lane >> 5;
     for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
         __syncthreads();
-        tn_store_lds(tile, t, reg);
+        tn_store_lds(tile, t, reg, m4);
         __syncthreads();
-        if (k0 + TN_BK < k_end) tn_load<T, VEC>(op, k_end, cols, k0 + TN_BK, col0, t, mean, reg);
+        if (k0 + TN_BK < k_end) {
+            tn_cursor_advance(cu, op);
+            tn_load<T, VEC>(op, cu, k_end, cols, k0 + TN_BK, col0, t, m4, reg);
+        }
 #pragma unroll
         for (int g = 0; g < TN_BK / 8; ++g) {
             float4 a[2], b[2];
@@ -353,14 +430,20 @@ __global__ void __launch_bounds__(256) syrk_tn_kernel(const void* const* __restr
     const int t = tid & 127;
     const int col0 = is_b ? n0 : m0;
     float* tile = is_b ? tB : tA;
-    float reg[2][4][4];
-    if (loader && k_begin < k_end) tn_load<T, VEC>(X, k_end, cols, k_begin, col0, t, mean, reg);
+    float reg[2][4][4], m4[4];
+    TnCursor cu;
+    tn_cursor_init(cu, X, k_begin, t);
+    tn_mean4(mean, cols, col0, t, m4);
+    if (loader && k_begin < k_end) tn_load<T, VEC>(X, cu, k_end, cols, k_begin, col0, t, m4, reg);
     const int i = lane & 31, h = lane >> 5;
     for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
         __syncthreads();
-        if (loader) tn_store_lds(tile, t, reg);
+        if (loader) tn_store_lds(tile, t, reg, m4);
         __syncthreads();
-        if (loader && k0 + TN_BK < k_end) tn_load<T, VEC>(X, k_end, cols, k0 + TN_BK, col0, t, mean, reg);
+        if (loader && k0 + TN_BK < k_end) {
+            tn_cursor_advance(cu, X);
+            tn_load<T, VEC>(X, cu, k_end, cols, k0 + TN_BK, col0, t, m4, reg);
+        }
 #pragma unroll
         for (int g = 0; g < TN_BK / 8; ++g) {
             float4 a[2], b[2];
@@ -436,6 +519,61 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(GemmOperand X, int 
         partial[((long)blockIdx.z * parts + blockIdx.y) * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
+// Vector form (unit column stride, 16-byte aligned rows): a wave reads 1 KB of one row per load and keeps four
+// rows in flight; block = 4 row groups x 64 column quads; grid = (ceil(cols/256), parts, batch).
+__device__ __forceinline__ float4 load4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float4 load4(const __hip_bfloat16* p) {
+    const uint2 v = *(const uint2*)p;      // four bf16: widen by shifting into the high half
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_partial_vec_kernel(GemmOperand X, int rows, int cols, int parts,
+                                                                 float* __restrict__ partial,
+                                                                 const void* const* __restrict__ ptrs) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6, c = (blockIdx.x * 64 + lane) * 4;
+    const T* base = ptrs ? (const T*)ptrs[blockIdx.z] : (const T*)X.ptr + (long)blockIdx.z * X.batch_stride;
+    const int per = (rows + parts - 1) / parts;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    const bool active = c < cols;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (batch item, row in item) of this wave's current row: advanced without division
+    int r = r0 + rg;
+    int b = r / X.rows_per_batch, n = r - b * X.rows_per_batch;
+    long off = (long)b * X.sb + (long)n * X.sn;
+    const long wrap = X.sb - (long)X.rows_per_batch * X.sn;
+    auto next = [&]() {
+        r += 4; n += 4; off += 4 * X.sn;
+        while (n >= X.rows_per_batch) { n -= X.rows_per_batch; off += wrap; }     // wave-uniform
+    };
+    while (r + 12 < r1) {
+        long o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { o[u] = off; next(); }
+        if (active) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = load4(base + o[u] + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+    }
+    while (r < r1) {
+        if (active) { const float4 v = load4(base + off + c); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        next();
+    }
+    red[rg][lane] = s;
+    __syncthreads();
+    if (rg == 0 && active) {
+        const float4 a = red[0][lane], b4 = red[1][lane], c4 = red[2][lane], d4 = red[3][lane];
+        *(float4*)(partial + ((long)blockIdx.z * parts + blockIdx.y) * cols + c) =
+            make_float4((a.x + b4.x) + (c4.x + d4.x), (a.y + b4.y) + (c4.y + d4.y), (a.z + b4.z) + (c4.z + d4.z),
+                        (a.w + b4.w) + (c4.w + d4.w));
+    }
+}
+
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int cols, int parts,
                                                            float inv_rows, float* __restrict__ mean) {
     // block = 64 columns x 4 part groups (fixed summation order: deterministic)
@@ -456,6 +594,15 @@ __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restri
 using namespace basd;
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <typename T>
+static void launch_colsum(const GemmOperand& X, const void* const* ptrs, const void* x, int rows, int cols, int parts,
+                          int batch, bool vec, float* partial, hipStream_t stream) {
+    if (vec)
+        colsum_partial_vec_kernel<T><<<dim3((cols + 255) / 256, parts, batch), 256, 0, stream>>>(X, rows, cols, parts, partial, ptrs);
+    else
+        colsum_partial_kernel<T><<<dim3((cols + 63) / 64, parts, batch), 256, 0, stream>>>(X, rows, cols, parts, partial, ptrs);
+}
 
 extern "C" {
 
@@ -542,22 +689,37 @@ int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_p
                  int rows, int cols, int batch, int parts, float* partial, float* mean, hipStream_t stream) {
     BASD_CHECK_ARG(x && partial && mean && rows > 0 && cols > 0 && batch > 0 && parts >= 1);
     GemmOperand X{x, sb, sn, sd, rows_per_batch, batch_stride};
-    const dim3 grid((cols + 63) / 64, parts, batch);
-    if (dtype == BASD_DTYPE_F32) colsum_partial_kernel<float><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial);
-    else if (dtype == BASD_DTYPE_BF16) colsum_partial_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial);
+    const int esz = dtype == BASD_DTYPE_F32 ? 4 : 2;
+    const bool vec = sd == 1 && cols % 4 == 0 && ((uintptr_t)x & 15) == 0 && (sb * esz) % 16 == 0 &&
+                     (sn * esz) % 16 == 0 && (batch_stride * esz) % 16 == 0;
+    if (dtype == BASD_DTYPE_F32) launch_colsum<float>(X, nullptr, x, rows, cols, parts, batch, vec, partial, stream);
+    else if (dtype == BASD_DTYPE_BF16) launch_colsum<__hip_bfloat16>(X, nullptr, x, rows, cols, parts, batch, vec, partial, stream);
     else return BASD_EINVAL;
     colsum_final_kernel<<<dim3((cols + 63) / 64, batch), 256, 0, stream>>>(partial, cols, parts, 1.f / rows, mean);
     BASD_RETURN_LAST();
 }
 
+// Split count for the symmetric Gram launch: the grid (tile pairs x splits x matrices) should fill whole
+// rounds of the chip (256 CUs x 3 resident workgroups at this kernel's register budget) -- a 1.3-round
+// grid costs two rounds -- with every split keeping >= 8 k-chunks.  Among (near-)equal fills the smallest
+// split count wins (less slab traffic).
 int basd_syrk_splits(int krows, int cols, int n_mats) {
     const int tiles = (cols + BM - 1) / BM, pairs = tiles * (tiles + 1) / 2;
-    int s = (1024 + pairs * n_mats - 1) / (pairs * n_mats);
-    const int cap = krows / 64;
-    if (s > cap) s = cap;
-    if (s > 64) s = 64;
-    if (s < 1) s = 1;
-    return s;
+    const long w = (long)pairs * n_mats;
+    const int chunks = (krows + TN_BK - 1) / TN_BK;
+    int cap = chunks / 8;
+    if (cap > 64) cap = 64;
+    if (cap < 1) cap = 1;
+    const double slots = 768.0;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= cap; ++s) {
+        const double x = (double)(w * s) / slots;
+        const double rounds = x <= 1.0 ? 1.0 : (double)(long)(x + 0.999999);
+        const double eff = x / rounds;
+        if (eff > best_eff + 0.005) { best_eff = eff; best = s; }
+    }
+    return best;
 }
 
 // out[z] (cols x cols, symmetric) = scales[z] * (X_z - 1 means[z]^T)^T (X_z - 1 means[z]^T),  z < n_mats.
@@ -590,12 +752,14 @@ int basd_syrk_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long
 // means[z][c] = (1/rows) sum_r X_z(r, c) for a device table of same-layout matrices.
 //   partial: n_mats*parts*cols floats of scratch (parts from basd_colmean_parts).
 int basd_colmean_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long sd, int rows_per_batch, int rows,
-                       int cols, int n_mats, int parts, float* partial, float* means, hipStream_t stream) {
+                       int cols, int n_mats, int parts, float* partial, float* means, int vec_ok,
+                       hipStream_t stream) {
     BASD_CHECK_ARG(x_ptrs && partial && means && rows > 0 && cols > 0 && n_mats > 0 && parts >= 1);
     GemmOperand X{nullptr, sb, sn, sd, rows_per_batch, 0};
-    const dim3 grid((cols + 63) / 64, parts, n_mats);
-    if (dtype == BASD_DTYPE_F32) colsum_partial_kernel<float><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial, x_ptrs);
-    else if (dtype == BASD_DTYPE_BF16) colsum_partial_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(X, rows, cols, parts, partial, x_ptrs);
+    const int esz = dtype == BASD_DTYPE_F32 ? 4 : 2;
+    const bool vec = vec_ok && sd == 1 && cols % 4 == 0 && (sb * esz) % 16 == 0 && (sn * esz) % 16 == 0;
+    if (dtype == BASD_DTYPE_F32) launch_colsum<float>(X, x_ptrs, nullptr, rows, cols, parts, n_mats, vec, partial, stream);
+    else if (dtype == BASD_DTYPE_BF16) launch_colsum<__hip_bfloat16>(X, x_ptrs, nullptr, rows, cols, parts, n_mats, vec, partial, stream);
     else return BASD_EINVAL;
     colsum_final_kernel<<<dim3((cols + 63) / 64, n_mats), 256, 0, stream>>>(partial, cols, parts, 1.f / rows, means);
     BASD_RETURN_LAST();
