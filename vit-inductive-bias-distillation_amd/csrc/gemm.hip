@@ -711,14 +711,16 @@ int basd_syrk_splits(int krows, int cols, int n_mats) {
     if (cap > 64) cap = 64;
     if (cap < 1) cap = 1;
     const double slots = 768.0;
-    int best = 1;
-    double best_eff = 0.0;
-    for (int s = 1; s <= cap; ++s) {
+    auto fill = [&](int s) {
         const double x = (double)(w * s) / slots;
         const double rounds = x <= 1.0 ? 1.0 : (double)(long)(x + 0.999999);
-        const double eff = x / rounds;
-        if (eff > best_eff + 0.005) { best_eff = eff; best = s; }
-    }
+        return x / rounds;
+    };
+    double best_eff = 0.0;
+    for (int s = 1; s <= cap; ++s) best_eff = fill(s) > best_eff ? fill(s) : best_eff;
+    int best = cap;
+    for (int s = 1; s <= cap; ++s)
+        if (fill(s) >= 0.97 * best_eff) { best = s; break; }
     return best;
 }
 
