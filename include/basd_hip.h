@@ -111,8 +111,13 @@ int basd_sort_extract(const float* W, long batch_stride, int rows, int rows_tot,
 /* Householder tridiagonalisation A = Q T Q^T of `batch` symmetric n x n matrices (A destroyed):
  * first stage of the LAPACK path behind torch.linalg.eigvalsh (layer_selector.py:16) and the
  * Vt[:k] / S[:k] part of torch.linalg.svd (:36, :92).  d, e, tau: (batch, n); vh: (batch, n, n). */
+long basd_tridiag_workspace_bytes(int n, int batch);
+
+/* `work`: basd_tridiag_workspace_bytes(n, batch) bytes of 16-byte aligned device scratch.  A matrix is shared by
+ * up to 8 workgroups that exchange one 16-byte granule per row and step through it; its last 16 bytes hold an
+ * error word that is non-zero afterwards if a workgroup gave up waiting for its partners. */
 int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
-                 hipStream_t stream);
+                 void* work, hipStream_t stream);
 
 /* All eigenvalues (descending) of the tridiagonals by Sturm-sequence bisection. */
 int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, float* vals_desc, hipStream_t stream);

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _header_symbols():
     text = open(os.path.join(ROOT, "include", "basd_hip.h")).read()
-    return sorted(set(re.findall(r"^int (basd_\w+)\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|long) (basd_\w+)\(", text, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -29,7 +29,8 @@ SIGNATURES = {
     "basd_jacobi_workspace_ints": [i32, i32],
     "basd_jacobi_onesided": [vp, i64, i32, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp],
     "basd_sort_extract": [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
-    "basd_tridiag": [vp, i64, i32, i32, vp, vp, vp, vp, vp],
+    "basd_tridiag_workspace_bytes": [i32, i32],
+    "basd_tridiag": [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp],
     "basd_tridiag_eigenvalues": [vp, vp, i32, i32, vp, vp],
     "basd_tridiag_eigenvectors": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp],
     "basd_mp_rank": [vp, i32, i32, f64, i32, vp, vp, vp],
@@ -56,6 +57,9 @@ SIGNATURES = {
     "basd_eigvec_k2": [vp, vp, i32, i32, i32, vp, vp],
 }
 
+# sizing helpers declared `long` in include/basd_hip.h
+LONG_RESULTS = {"basd_tridiag_workspace_bytes"}
+
 _lock = threading.Lock()
 _lib = None
 
@@ -75,7 +79,7 @@ def load() -> C.CDLL:
             for name, argtypes in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.argtypes = argtypes
-                fn.restype = C.c_int
+                fn.restype = C.c_long if name in LONG_RESULTS else C.c_int
             _lib = lib
     return _lib
 

@@ -204,8 +204,9 @@ def tridiag_eigenvalues(G: torch.Tensor) -> TridiagState:
     vh = torch.empty((batch, n, n), **f32)
     vals = torch.empty((batch, n), **f32)
     st = _stream()
+    work = torch.empty((_lib.query("basd_tridiag_workspace_bytes", n, batch),), device=G.device, dtype=torch.uint8)
     _lib.call("basd_tridiag", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
-              vh.data_ptr(), st)
+              vh.data_ptr(), work.data_ptr(), st)
     _lib.call("basd_tridiag_eigenvalues", d.data_ptr(), e.data_ptr(), n, batch, vals.data_ptr(), st)
     return TridiagState(d, e, tau, vh, vals)
 

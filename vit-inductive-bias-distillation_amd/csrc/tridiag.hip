@@ -13,6 +13,7 @@
 // One workgroup per matrix; the matrix stays in L2 and is streamed row-wise (coalesced), the Householder
 // vector lives in LDS.  Everything is fp32, like LAPACK's ssytd2 / sstebz / sstein it restates.
 #include "basd_common.h"
+#include <stdlib.h>
 
 namespace basd {
 
@@ -36,10 +37,64 @@ __device__ __forceinline__ float block_sum_lds(float v, float* scratch, int nw) 
     return r;
 }
 
-template <bool VEC>
-__global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, long a_batch_stride, int n,
-                                                       float* __restrict__ d, float* __restrict__ e,
-                                                       float* __restrict__ tau_out, float* __restrict__ Vh) {
+// ---- hand-off of per-row results between the workgroups that share one matrix -----------------
+// One 16-byte granule per matrix row and step parity: (p_r, captured column entry, step tag, 0), written
+// and polled with sc1 accesses (served by L2 / fabric, never by a CU's L1).  The tag travels with the data,
+// so there is no separate flag, fence or atomic on the dependent chain: a consumer simply re-reads the
+// granule until it carries the tag of the current step.  Two parities suffice: a workgroup can only be one
+// step ahead of the slowest one (it needs that one's granules of the step in between).
+typedef float tri_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void granule_store(float4* p, float4 v) {
+    const tri_f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ float4 granule_load(const float4* p) {
+    tri_f32x4 x;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+    return make_float4(x.x, x.y, x.z, x.w);
+}
+
+// Eight row chunks in flight, then one wait: hipcc's schedulers otherwise sink each load next to its first
+// use and serialise the eight L2 round trips (observed: load, s_waitcnt vmcnt(0), arithmetic, next load ...).
+__device__ __forceinline__ void load8_rows(float4 (&a)[8], const float* p0, const float* p1, const float* p2,
+                                           const float* p3, const float* p4, const float* p5, const float* p6,
+                                           const float* p7) {
+    tri_f32x4 x0, x1, x2, x3, x4, x5, x6, x7;
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off\n\t"
+        "global_load_dwordx4 %1, %9, off\n\t"
+        "global_load_dwordx4 %2, %10, off\n\t"
+        "global_load_dwordx4 %3, %11, off\n\t"
+        "global_load_dwordx4 %4, %12, off\n\t"
+        "global_load_dwordx4 %5, %13, off\n\t"
+        "global_load_dwordx4 %6, %14, off\n\t"
+        "global_load_dwordx4 %7, %15, off\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+        : "memory");
+    a[0] = make_float4(x0.x, x0.y, x0.z, x0.w); a[1] = make_float4(x1.x, x1.y, x1.z, x1.w);
+    a[2] = make_float4(x2.x, x2.y, x2.z, x2.w); a[3] = make_float4(x3.x, x3.y, x3.z, x3.w);
+    a[4] = make_float4(x4.x, x4.y, x4.z, x4.w); a[5] = make_float4(x5.x, x5.y, x5.z, x5.w);
+    a[6] = make_float4(x6.x, x6.y, x6.z, x6.w); a[7] = make_float4(x7.x, x7.y, x7.z, x7.w);
+}
+
+constexpr int TRI_RB = 8;      // rows per group: RB independent load streams keep L2 latency covered
+constexpr int TRI_BLK = 32;    // rows per ownership block (4 groups)
+
+// grid = P * batch_pad workgroups of 1024 threads; workgroup id = p * batch_pad + z works on matrix z as
+// member p of P (ids that differ by a multiple of 8 are dealt to one XCD: the P members share an L2).
+// Row blocks of 32 are owned block-cyclically (block b -> member b % P) for the whole factorisation: a
+// member reads and writes only its own rows of A.  Per step every member forms the reflector redundantly
+// (same inputs, same arithmetic, bit-identical), runs the fused update + matrix-vector pass over its rows,
+// publishes (p_r, next column entry) of those rows and collects the other members' -- the only exchange.
+// P == 1 degenerates to the single-workgroup factorisation (no exchange at all).
+template <bool VEC, bool FULL>
+__global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, long a_batch_stride, int n, int batch,
+                                                       int batch_pad, int P, float* __restrict__ d,
+                                                       float* __restrict__ e, float* __restrict__ tau_out,
+                                                       float* __restrict__ Vh, float4* __restrict__ xg,
+                                                       int* __restrict__ err) {
     // ONE pass over the trailing block per step: the rank-2 update of step j-1 is applied lazily while the
     // rows are read for the matrix-vector product of step j (a' = a - v_r w_c - w_r v_c ; p_r += a' u_c), and
     // the column the next reflector is built from is captured on the way.  All vectors are indexed by ABSOLUTE
@@ -50,16 +105,23 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
     float* u = sm + 2 * n;     // current reflector
     float* pw = sm + 3 * n;    // current p, then current w
     float* col = sm + 4 * n;   // column j of the up-to-date matrix (rows >= j)
+    float* cap4 = sm + 5 * n;  // 4 n: per row, the aligned 4-column chunk holding column r0 as captured by the pass
     __shared__ float red[32];
-    __shared__ float s_tau, s_beta;
-    const int z = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    const int z = blockIdx.x % batch_pad, p = blockIdx.x / batch_pad;
+    if (z >= batch) return;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6;
+    // wave index as a scalar: everything derived from it (row bases, per-row reflector entries) then lives in
+    // SGPRs, and the rows are addressed as scalar base + one shared per-lane column offset
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* Az = A + (long)z * a_batch_stride;
     float* dz = d + (long)z * n;
     float* ez = e + (long)z * n;
     float* tz = tau_out + (long)z * n;
     float* Vz = Vh + (long)z * n * n;
-    constexpr int RB = 8;      // rows per group: RB independent load streams keep L2 latency covered;
-                               // group g (rows g*RB ..) belongs to wave g % nw for the whole factorisation
+    float4* xz = xg + (long)z * 2 * n;
+    constexpr int RB = TRI_RB;
+    const int nblk = (n + TRI_BLK - 1) / TRI_BLK;
+    int budget = 1 << 22;      // polls before a member gives up on its partners (never reached when all are resident)
     for (int r = tid; r < n; r += nthr) {
         v[r] = 0.f;
         w[r] = 0.f;
@@ -72,48 +134,61 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         for (int r = r0 + 1 + tid; r < n; r += nthr) part = fmaf(col[r], col[r], part);
         const float xn2 = block_sum_lds(part, red, nw);
         const float alpha = col[r0];
-        if (tid == 0) {
-            float tau = 0.f, beta = alpha;
-            if (xn2 > 0.f) {
-                beta = -copysignf(sqrtf(fmaf(alpha, alpha, xn2)), alpha);
-                tau = (beta - alpha) / beta;
-            }
-            s_tau = tau;
-            s_beta = beta;
+        // every thread forms tau / beta itself (same inputs everywhere): no broadcast, no extra barrier
+        float tau = 0.f, beta = alpha;
+        if (xn2 > 0.f) {
+            beta = -copysignf(sqrtf(fmaf(alpha, alpha, xn2)), alpha);
+            tau = (beta - alpha) / beta;
+        }
+        if (p == 0 && tid == 0) {
             dz[j] = col[j];
             ez[j] = beta;
             tz[j] = tau;
         }
-        lds_barrier();
-        const float tau = s_tau;
-        const float scal = tau != 0.f ? 1.f / (alpha - s_beta) : 0.f;
+        const float scal = tau != 0.f ? 1.f / (alpha - beta) : 0.f;
+        const bool writes_v = p == j % P;     // reflector rows for the back-transformation: members take turns
         for (int r = tid; r < n; r += nthr) {
             const float ur = r < r0 ? 0.f : (r == r0 ? 1.f : col[r] * scal);
             u[r] = ur;
-            Vz[(long)j * n + r] = ur;          // reflector row for the back-transformation
+            if (writes_v) Vz[(long)j * n + r] = ur;
         }
         lds_barrier();
         const int c_begin = VEC ? (r0 & ~3) : r0;
-        const int g_first = r0 / RB;
-        for (int g = g_first + ((wave - g_first % nw + nw) % nw); g * RB < n; g += nw) {
-            const int rb = g * RB;
+        // my live row groups: local group lg -> block (lg / 4) * P + p, group lg % 4 of it; wave lg % nw owns it
+        const int b_first = r0 / TRI_BLK;
+        const int lb0 = b_first > p ? (b_first - p + P - 1) / P : 0;
+        for (int lg = lb0 * 4 + ((wave - (lb0 * 4) % nw + nw) % nw);; lg += nw) {
+            const int b = (lg >> 2) * P + p;
+            if (b >= nblk) break;
+            const int rb = (b * 4 + (lg & 3)) * RB;
+            if (rb >= n) break;
+            if (rb + RB <= r0) continue;
+            // FULL (n a multiple of the group size, vector path): no predicates at all.  Rows of the first live
+            // group that lie above r0 are already reduced; they are carried along (their pending update is a
+            // finished row's business, their p and captured entries land in slots nobody reads), so the whole
+            // chunk iteration is one basic block: eight loads in flight, then arithmetic, then eight stores.
             float acc[RB], vr[RB], wr[RB];
             bool live[RB];
 #pragma unroll
             for (int q = 0; q < RB; ++q) {
-                live[q] = rb + q >= r0 && rb + q < n;
+                live[q] = FULL || (rb + q >= r0 && rb + q < n);
                 acc[q] = 0.f;
-                vr[q] = live[q] ? v[rb + q] : 0.f;
-                wr[q] = live[q] ? w[rb + q] : 0.f;
+                vr[q] = live[q] ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v[rb + q]))) : 0.f;
+                wr[q] = live[q] ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w[rb + q]))) : 0.f;
             }
             if (VEC) {
                 for (int c = c_begin + 4 * lane; c < n; c += 256) {
                     const float4 vv = *(const float4*)(v + c), ww = *(const float4*)(w + c);
                     const float4 uu = *(const float4*)(u + c);
                     float4 a[RB];
+                    if (FULL) {
+                        const float* rp = Az + (long)rb * n + c;
+                        load8_rows(a, rp, rp + n, rp + 2 * n, rp + 3 * n, rp + 4 * n, rp + 5 * n, rp + 6 * n, rp + 7 * n);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < RB; ++q)
-                        if (live[q]) a[q] = *(const float4*)(Az + (long)(rb + q) * n + c);
+                        for (int q = 0; q < RB; ++q)
+                            if (live[q]) a[q] = *(const float4*)(Az + (long)(rb + q) * n + c);
+                    }
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
                         if (live[q]) {
@@ -121,13 +196,16 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
                             a[q].y -= fmaf(vr[q], ww.y, wr[q] * vv.y);
                             a[q].z -= fmaf(vr[q], ww.z, wr[q] * vv.z);
                             a[q].w -= fmaf(vr[q], ww.w, wr[q] * vv.w);
-                            *(float4*)(Az + (long)(rb + q) * n + c) = a[q];
                             acc[q] = fmaf(a[q].x, uu.x, fmaf(a[q].y, uu.y, fmaf(a[q].z, uu.z, fmaf(a[q].w, uu.w, acc[q]))));
-                            if (c == c_begin) {      // the chunk holding column r0: capture the next column
-                                const int off = r0 - c_begin;
-                                col[rb + q] = off == 0 ? a[q].x : off == 1 ? a[q].y : off == 2 ? a[q].z : a[q].w;
-                            }
                         }
+                    }
+#pragma unroll
+                    for (int q = 0; q < RB; ++q)
+                        if (live[q]) *(float4*)(Az + (long)(rb + q) * n + c) = a[q];
+                    if (c == c_begin) {      // the chunk holding column r0: capture it for the next reflector
+#pragma unroll
+                        for (int q = 0; q < RB; ++q)
+                            if (live[q]) *(float4*)(cap4 + 4 * (rb + q)) = a[q];
                     }
                 }
             } else {
@@ -139,7 +217,7 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
                             const float an = Az[(long)(rb + q) * n + c] - fmaf(vr[q], wc, wr[q] * vc);
                             Az[(long)(rb + q) * n + c] = an;
                             acc[q] = fmaf(an, uc, acc[q]);
-                            if (c == r0) col[rb + q] = an;
+                            if (c == r0) cap4[4 * (rb + q)] = an;
                         }
                     }
                 }
@@ -151,6 +229,31 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
             }
         }
         lds_barrier();
+        const int coff = r0 - c_begin;      // position of column r0 inside the captured chunk
+        if (P > 1) {
+            float4* xp = xz + (long)(j & 1) * n;
+            const float tag = __int_as_float(j);
+            // publish my live blocks: wave (local block % nw), lanes 0..31 -> 512 contiguous bytes per store
+            if (lane < TRI_BLK) {
+                for (int lb = lb0 + wave; lb * P + p < nblk; lb += nw) {
+                    const int r = (lb * P + p) * TRI_BLK + lane;
+                    if (r < n) granule_store(xp + r, make_float4(pw[r], cap4[4 * r + coff], tag, 0.f));
+                }
+            }
+            // collect the other members' rows
+            for (int r = b_first * TRI_BLK + tid; r < n; r += nthr) {
+                if ((r / TRI_BLK) % P == p) continue;
+                float4 g = granule_load(xp + r);
+                while (__float_as_int(g.z) != j && budget > 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    --budget;
+                    g = granule_load(xp + r);
+                }
+                pw[r] = g.x;
+                cap4[4 * r + coff] = g.y;
+            }
+            lds_barrier();
+        }
         float gp = 0.f;
         for (int r = r0 + tid; r < n; r += nthr) gp = fmaf(pw[r], u[r], gp);
         const float gamma = -0.5f * tau * block_sum_lds(gp, red, nw);
@@ -160,7 +263,7 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         for (int r = tid; r < n; r += nthr) {
             const float ur = u[r];
             const float wn = r >= r0 ? fmaf(gamma, ur, pw[r]) : 0.f;
-            if (r >= r0) col[r] -= fmaf(ur, w0, wn);     // u[r0] = 1
+            if (r >= r0) col[r] = cap4[4 * r + coff] - fmaf(ur, w0, wn);     // u[r0] = 1
             v[r] = ur;
             w[r] = wn;
             pw[r] = wn;
@@ -168,12 +271,15 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         lds_barrier();
     }
     __syncthreads();
-    if (tid == 0) {
-        dz[n - 1] = col[n - 1];
-        ez[n - 1] = 0.f;
-        tz[n - 1] = 0.f;
+    if (budget <= 0) *err = 1;
+    if (p == 0) {
+        if (tid == 0) {
+            dz[n - 1] = col[n - 1];
+            ez[n - 1] = 0.f;
+            tz[n - 1] = 0.f;
+        }
+        for (int c = tid; c < n; c += nthr) Vz[(long)(n - 1) * n + c] = 0.f;
     }
-    for (int c = tid; c < n; c += nthr) Vz[(long)(n - 1) * n + c] = 0.f;
 }
 
 // ---------------------------------------------------------------------------
@@ -499,13 +605,42 @@ extern "C" {
 
 // Householder tridiagonalisation of `batch` symmetric matrices (destroyed).  d, e, tau: (batch, n);
 // vh: (batch, n, n) reflector rows.
+// Members per matrix: up to one 32-row block per member (measured on MI355X at n = 384, 6 matrices: 3.12 ms with
+// 1 member, 1.95 with 4, 1.63 with 12), while every workgroup of the launch is certainly resident (the members spin on each other): at most
+// 128 workgroups per launch, so that two concurrent factorisations still fit the 256 CUs.
+static int tridiag_members(int n, int batch) {
+    const int nblk = (n + TRI_BLK - 1) / TRI_BLK;
+    int p = nblk;
+    if (const char* s = getenv("BASD_TRIDIAG_MEMBERS")) p = atoi(s);
+    if (p > 16) p = 16;
+    while (p > 1 && p * batch > 128) --p;
+    if (p > nblk) p = nblk;
+    return p < 1 ? 1 : p;
+}
+
+long basd_tridiag_workspace_bytes(int n, int batch) {
+    // per matrix: 2 parities x n granules of 16 bytes; plus one error word (padded to 16 bytes)
+    return (long)batch * 2 * n * 16 + 16;
+}
+
 int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
-                 hipStream_t stream) {
-    BASD_CHECK_ARG(a && d && e && tau && vh && n > 1 && batch > 0);
+                 void* work, hipStream_t stream) {
+    BASD_CHECK_ARG(a && d && e && tau && vh && work && n > 1 && batch > 0);
+    BASD_CHECK_ARG((((uintptr_t)work) & 15) == 0);
     if (n > 4096) return BASD_EUNSUPPORTED;
     const bool vec = (n & 3) == 0 && (a_batch_stride & 3) == 0 && (((uintptr_t)a) & 15) == 0;
-    if (vec) tridiag_kernel<true><<<batch, 1024, sizeof(float) * 5 * (size_t)n, stream>>>(a, a_batch_stride, n, d, e, tau, vh);
-    else tridiag_kernel<false><<<batch, 1024, sizeof(float) * 5 * (size_t)n, stream>>>(a, a_batch_stride, n, d, e, tau, vh);
+    const int P = tridiag_members(n, batch);
+    const int batch_pad = P > 1 ? (batch + 7) & ~7 : batch;
+    const long gran_bytes = (long)batch * 2 * n * 16;
+    float4* xg = (float4*)work;
+    int* err = (int*)((char*)work + gran_bytes);
+    // tags start at -1 (no step); error word at 0
+    if (hipMemsetAsync(work, 0xFF, gran_bytes, stream) != hipSuccess) return BASD_EINVAL;
+    if (hipMemsetAsync(err, 0, 16, stream) != hipSuccess) return BASD_EINVAL;
+    const size_t lds = sizeof(float) * 9 * (size_t)n;
+    if (vec && (n & 7) == 0) tridiag_kernel<true, true><<<P * batch_pad, 1024, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
+    else if (vec) tridiag_kernel<true, false><<<P * batch_pad, 1024, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
+    else tridiag_kernel<false, false><<<P * batch_pad, 1024, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
     BASD_RETURN_LAST();
 }
 
