@@ -178,7 +178,29 @@ def test_resample_matches_interpolate(dev):
         assert (x.grad - ref_in.grad).abs().max() < 1e-6 * ref_in.grad.abs().max()
 
 
-@pytest.mark.parametrize("n,k", [(384, 48), (192, 20), (768, 80), (100, 100)])
+@pytest.mark.parametrize("n", [384, 100, 45, 33])
+def test_tridiag_member_count_is_invisible(dev, n, monkeypatch):
+    """The workgroups sharing a matrix exchange rows of identical arithmetic: d, e, tau and the reflectors are
+    bit-identical whatever the member count (vector+full, vector+ragged and scalar kernels)."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(7 * n)
+    x = torch.randn(3, 4 * n, n, generator=g)
+    G0 = (x.transpose(1, 2) @ x).to(dev)
+    outs = []
+    for members in ("1", "2", "5", "16"):
+        monkeypatch.setenv("BASD_TRIDIAG_MEMBERS", members)
+        ts = ops.tridiag_eigenvalues(G0.clone())
+        assert int(ts.err.item()) == 0
+        outs.append(ts)
+    for ts in outs[1:]:
+        for name in ("d", "e", "tau", "vh", "vals"):
+            assert torch.equal(getattr(ts, name), getattr(outs[0], name)), (name, n)
+    # and it is a tridiagonalisation: eigenvalues of T == eigenvalues of G
+    ref = torch.linalg.eigvalsh(G0.double().cpu()).flip(1)
+    assert ((outs[-1].vals.double().cpu() - ref).abs().max(dim=1).values / ref[:, 0]).max() < 3e-6
+
+
+@pytest.mark.parametrize("n,k", [(384, 48), (192, 20), (768, 80), (100, 100), (45, 10)])
 def test_tridiag_eigensolver(dev, n, k):
     """Householder tridiagonalisation + Sturm bisection + inverse iteration against fp64 eigh."""
     from basd_amd import ops

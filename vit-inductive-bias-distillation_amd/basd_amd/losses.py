@@ -336,7 +336,13 @@ class GrassmannianLayerSelector(nn.Module):
         d_s = self.student_dim
         ranks_dev, o_c, E, L = (st[k] for k in ("ranks_dev", "o_c", "E", "L"))
         dev = ranks_dev.device
-        ranks = [int(r) for r in ranks_dev.tolist()]
+        # the step's one read-back: the ranks, and behind them the status words of the eigen-solves
+        errs = [st[k].err for k in ("t_ts", "s_ts") if k in st and st[k].err is not None]
+        host = torch.cat([ranks_dev.to(torch.int32), *errs]).tolist() if errs else ranks_dev.tolist()
+        ranks = [int(r) for r in host[:L]]
+        if any(host[L:]):
+            raise RuntimeError("basd_tridiag: workgroups sharing a matrix timed out waiting for each other "
+                               "(device oversubscribed?); eigen-solve results are invalid")
         for k, r in zip(keys, ranks):
             self.subspace_ranks[k] = r
         if min(ranks) == 0:
