@@ -122,10 +122,14 @@ def _record_stream(obj, stream) -> None:
 
 
 class _ProcrustesLayers(torch.autograd.Function):
-    """(mix (E, L), has_cls, teachers, attns, *students) -> per-layer loss (E,)."""
+    """(mix (E, L), has_cls, eager, teachers, attns, *students) -> per-layer loss (E,).
+
+    ``eager``: queue the student-token gradient kernels (for a unit upstream gradient) right behind the forward
+    kernels.  The gradient is linear in the upstream scalar, so backward only scales -- used where the caller is
+    about to block on a read-back anyway, which takes the gradient launches off the host's critical path."""
 
     @staticmethod
-    def forward(ctx, mix, has_cls, teachers, attns, *students):
+    def forward(ctx, mix, has_cls, eager, teachers, attns, *students):
         need_bwd = any(s.requires_grad for s in students)
         # one teacher layer: softmax over one logit is constant, d loss / d mix is exactly 0
         need_mix = bool(mix.requires_grad and mix.shape[1] > 1)
@@ -136,6 +140,10 @@ class _ProcrustesLayers(torch.autograd.Function):
         ctx.save_for_backward(*students)
         ctx.need_mix = need_mix
         ctx.mix_shape = tuple(mix.shape)
+        ctx.unit_grads = None
+        if eager and need_bwd and not need_mix and pc.k_prime is not None:
+            ones = torch.ones((len(students),), device=pc.loss_b.device, dtype=torch.float32)
+            ctx.unit_grads = ops.procrustes_student_grads(list(students), pc, ones)
         return pc.loss_b.mean(dim=1)
 
     @staticmethod
@@ -146,18 +154,22 @@ class _ProcrustesLayers(torch.autograd.Function):
         if pc.k_prime is None:
             if ctx.needs_input_grad[0]:
                 g_mix = torch.zeros(ctx.mix_shape, device=grad_layers.device)
-            return (g_mix, None, None, None) + (None,) * ctx.n_students
+            return (g_mix, None, None, None, None) + (None,) * ctx.n_students
         if ctx.need_mix:
             kt, tnorm2 = ops.procrustes_teacher_factor(pc)
             grads, gomega = ops.procrustes_student_grads(list(students), pc, grad_layers, tnorm2)
             g_mix = ops.procrustes_mix_grads(pc, kt, gomega, grad_layers)
         else:
-            grads = ops.procrustes_student_grads(list(students), pc, grad_layers)
+            if ctx.unit_grads is not None:
+                gl = grad_layers.float()
+                grads = [u * gl[e] for e, u in enumerate(ctx.unit_grads)]
+            else:
+                grads = ops.procrustes_student_grads(list(students), pc, grad_layers)
             if ctx.needs_input_grad[0]:
                 g_mix = torch.zeros(ctx.mix_shape, device=grad_layers.device)
-        grads = [g.to(s.dtype) if ctx.needs_input_grad[4 + i] else None
+        grads = [g.to(s.dtype) if ctx.needs_input_grad[5 + i] else None
                  for i, (g, s) in enumerate(zip(grads, students))]
-        return (g_mix, None, None, None, *grads)
+        return (g_mix, None, None, None, None, *grads)
 
 
 class _GrassmannDistance(torch.autograd.Function):
@@ -203,7 +215,7 @@ def geometric_relational_loss(
     if teacher_tokens.requires_grad or teacher_attn.requires_grad:
         raise NotImplementedError("gradients w.r.t. teacher tokens / attention are not implemented yet")
     mix = torch.ones((1, 1), device=student_tokens.device, dtype=torch.float32)
-    return _ProcrustesLayers.apply(mix, bool(has_cls_token), [teacher_tokens], [teacher_attn], student_tokens)[0]
+    return _ProcrustesLayers.apply(mix, bool(has_cls_token), False, [teacher_tokens], [teacher_attn], student_tokens)[0]
 
 
 # --------------------------------------------------------------------------- #
@@ -267,6 +279,14 @@ class GrassmannianLayerSelector(nn.Module):
         ranks_dev = ops.mp_rank_device(vals_u, M, self.student_dim, cap=self.student_dim - 1)   # :74
         for k, r in zip(keys, ranks_dev.tolist()):
             self.subspace_ranks[k] = int(r)
+
+    def _proj_s_transposed(self) -> torch.Tensor:
+        """proj_s^T, fp32 contiguous; cached (the buffer only changes on load_state_dict / .to())."""
+        key = (self.proj_s.data_ptr(), self.proj_s._version, self.proj_s.dtype)
+        if getattr(self, "_proj_s_t_key", None) != key:
+            self._proj_s_t = self.proj_s.float().t().contiguous()
+            self._proj_s_t_key = key
+        return self._proj_s_t
 
     # ---- distances + mixing weights ------------------------------------------------------
     @torch.no_grad()
@@ -339,6 +359,7 @@ class GrassmannianLayerSelector(nn.Module):
         # the step's one read-back: the ranks, and behind them the status words of the eigen-solves
         errs = [st[k].err for k in ("t_ts", "s_ts") if k in st and st[k].err is not None]
         host = torch.cat([ranks_dev.to(torch.int32), *errs]).tolist() if errs else ranks_dev.tolist()
+        ops.trace("ranks_read")
         ranks = [int(r) for r in host[:L]]
         if any(host[L:]):
             raise RuntimeError("basd_tridiag: workgroups sharing a matrix timed out waiting for each other "
@@ -375,15 +396,19 @@ class GrassmannianLayerSelector(nn.Module):
                 t.record_stream(cur)
         sw = ops.sqrt_clamp(vals_c[:, :kmax])                      # singular values S[:k]   (:36-37)
         v_s = v_all[:, :kmax]                                      # (E, kmax, d_s) rows = Vt_s[:kmax]
-        proj_s_t = self.proj_s.float().t().contiguous()
-        u_rot = ops.gemm_nt(u_t.view(L * kmax, d_s), proj_s_t).view(L, kmax, d_s)   # rows: (proj_s^T u)^T
+        u_rot = ops.gemm_nt(u_t.view(L * kmax, d_s), self._proj_s_transposed()).view(L, kmax, d_s)   # rows: (proj_s^T u)^T
         cos = torch.empty((E, L, kmax, kmax), device=dev, dtype=torch.float32)
-        for e in range(E):
-            a = v_s[e] if v_s[e].is_contiguous() else v_s[e].contiguous()
-            ops.gemm_nt(a, u_rot[0], out=cos[e], batch=L, a_batch_stride=0, b_batch_stride=kmax * d_s,
-                        rows=kmax, n_cols=kmax)                    # Vt_s[:k] @ U_t   (:99)
-        k_arr = ranks_dev.repeat(E).contiguous()
-        sw_index = torch.arange(L, device=dev, dtype=torch.int32).repeat(E).contiguous()
+        if L == 1 and v_s.is_contiguous():
+            # one launch over the extraction layers: Vt_s[e][:k] @ U_t   (:99)
+            ops.gemm_nt(v_s[0], u_rot[0], out=cos, batch=E, a_batch_stride=kmax * d_s, b_batch_stride=0,
+                        rows=kmax, n_cols=kmax)
+        else:
+            for e in range(E):
+                a = v_s[e] if v_s[e].is_contiguous() else v_s[e].contiguous()
+                ops.gemm_nt(a, u_rot[0], out=cos[e], batch=L, a_batch_stride=0, b_batch_stride=kmax * d_s,
+                            rows=kmax, n_cols=kmax)                # Vt_s[:k] @ U_t   (:99)
+        k_arr = ranks_dev if E == 1 else (ranks_dev.expand(E) if L == 1 else ranks_dev.repeat(E)).contiguous()
+        sw_index = ops._device_consts(tuple(range(L)) * E, torch.int32, dev)
         if not want_grad:
             sigma = ops.jacobi_onesided(cos.view(E * L, kmax, kmax), kmax, n_arr=k_arr)
             return ops.grassmann_distance(sigma, k_arr, sw, sw_index).view(E, L), None   # (:100-105)
@@ -507,8 +532,7 @@ class BASDLoss(nn.Module):
         all_teacher_tokens: dict[int, torch.Tensor],
         all_teacher_attns: dict[int, torch.Tensor],
     ) -> torch.Tensor:
-        ce_loss = self.base_criterion(student_output, targets)
-
+        ops.trace("fwd_in")
         keys = sorted(all_teacher_tokens.keys())
         students = [student_intermediates[l] for l in self.token_layers]
         for s in students:
@@ -535,9 +559,13 @@ class BASDLoss(nn.Module):
                 t.record_stream(side2)
             with torch.cuda.stream(side):
                 spectra = sel._spectra_async(students, teachers, student_stream=side2)
+            ops.trace("chains_queued")
+            ce_loss = self.base_criterion(student_output, targets)     # queued behind the chains' first launches
             tau = sel.temperatures.float()
             mix = torch.softmax(torch.zeros((len(students), 1), device=tau.device) / tau.unsqueeze(1), dim=1)
-            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
+            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), True, teachers, attns,
+                                                 *students)
+            ops.trace("procrustes_queued")
 
             def selector_tail():
                 # eigenvectors + principal angles on a third stream: the next step's eigen-solve chains do not
@@ -552,8 +580,10 @@ class BASDLoss(nn.Module):
                     sel._angles_from_spectra(spectra, keys)
         else:
             selector_tail = None
+            ce_loss = self.base_criterion(student_output, targets)
             mix = sel.mixing_weights(students, keys, teachers)
-            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), teachers, attns, *students)
+            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), False, teachers, attns,
+                                                 *students)
         geo_loss = geo_layers.mean()
 
         vals = [ce_loss, geo_loss]
@@ -563,6 +593,8 @@ class BASDLoss(nn.Module):
         w = inv / inv.sum()
         self.last_components = {"ce": ce_loss.detach(), "geo_layers": geo_layers.detach(), "mix": mix.detach()}
         total = sum(w[i] * vals[i] for i in range(len(vals)))
+        ops.trace("combine_queued")
         if selector_tail is not None:
             selector_tail()
+        ops.trace("fwd_out")
         return total

@@ -51,6 +51,16 @@ def _ptr(t: torch.Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
 
+# Host-side timeline of a step (tools/host_timeline.py): list of (label, perf_counter) when switched on.
+HOST_TRACE: list | None = None
+
+
+def trace(label: str) -> None:
+    if HOST_TRACE is not None:
+        import time
+        HOST_TRACE.append((label, time.perf_counter()))
+
+
 def _tok3(x: torch.Tensor) -> tuple[int, int, int, int, int, int]:
     """(ptr, dtype, sb, sn, sd, rows_per_batch) of a (B, N, D) or (M, D) view."""
     if x.dim() == 2:
