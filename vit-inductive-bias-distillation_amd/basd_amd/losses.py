@@ -10,6 +10,7 @@ raises ``RuntimeError`` (no fallback path exists).
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -520,7 +521,9 @@ class BASDLoss(nn.Module):
     def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
         key = (str(device), index)
         if key not in self._side_streams:
-            self._side_streams[key] = torch.cuda.Stream(device=device)
+            # the eigen-solve chains (0, 1) are the step's critical path: high priority; the tail (2) is not
+            prio = -1 if index < 2 and os.environ.get("BASD_CHAIN_PRIORITY", "1") == "1" else 0
+            self._side_streams[key] = torch.cuda.Stream(device=device, priority=prio)
         return self._side_streams[key]
 
     @torch.compiler.disable

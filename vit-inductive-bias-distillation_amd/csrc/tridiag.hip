@@ -608,6 +608,8 @@ extern "C" {
 // Members per matrix: up to one 32-row block per member (measured on MI355X at n = 384, 6 matrices: 3.12 ms with
 // 1 member, 1.95 with 4, 1.63 with 12), while every workgroup of the launch is certainly resident (the members spin on each other): at most
 // 128 workgroups per launch, so that two concurrent factorisations still fit the 256 CUs.
+static int nblk_of(int n) { return (n + TRI_BLK - 1) / TRI_BLK; }
+
 static int tridiag_members(int n, int batch) {
     const int nblk = (n + TRI_BLK - 1) / TRI_BLK;
     int p = nblk;
@@ -638,9 +640,13 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
     if (hipMemsetAsync(work, 0xFF, gran_bytes, stream) != hipSuccess) return BASD_EINVAL;
     if (hipMemsetAsync(err, 0, 16, stream) != hipSuccess) return BASD_EINVAL;
     const size_t lds = sizeof(float) * 9 * (size_t)n;
-    if (vec && (n & 7) == 0) tridiag_kernel<true, true><<<P * batch_pad, 1024, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
-    else if (vec) tridiag_kernel<true, false><<<P * batch_pad, 1024, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
-    else tridiag_kernel<false, false><<<P * batch_pad, 1024, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
+    // a member with one 32-row block keeps only four waves busy in the pass: fewer waves make the barriers
+    // cheaper (n = 384, 12 members: 1.63 ms with 1024 threads, 1.55 with 512, 1.66 with 256)
+    int threads = (P > 1 && (nblk_of(n) + P - 1) / P <= 1) ? 512 : 1024;
+    if (const char* s = getenv("BASD_TRIDIAG_THREADS")) threads = atoi(s);
+    if (vec && (n & 7) == 0) tridiag_kernel<true, true><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
+    else if (vec) tridiag_kernel<true, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
+    else tridiag_kernel<false, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
     BASD_RETURN_LAST();
 }
 
