@@ -173,6 +173,30 @@ class _ProcrustesLayers(torch.autograd.Function):
         return (g_mix, None, None, None, None, *grads)
 
 
+class _UWSOCombine(torch.autograd.Function):
+    """(ce, geo_layers (E,)) -> w_ce * ce + w_geo * mean(geo_layers), UW-SO weights w_i = (1/L_i) / sum_j (1/L_j)
+    computed from the detached loss values (combined.py:78-85).  One autograd node instead of the eight the
+    elementwise expression builds: the weights carry no gradient, so the backward is two scalings."""
+
+    @staticmethod
+    def forward(ctx, ce, geo_layers):
+        geo = geo_layers.mean()
+        vals = torch.stack([ce, geo.to(ce.dtype)])
+        eps = torch.finfo(ce.dtype).eps
+        inv = 1.0 / vals.clamp(min=eps)
+        w = inv / inv.sum()
+        ctx.save_for_backward(w)
+        ctx.n_layers = geo_layers.numel()
+        ctx.geo_dtype = geo_layers.dtype
+        return (w * vals).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        gw = g * w
+        return gw[0], (gw[1] / ctx.n_layers).to(ctx.geo_dtype).expand(ctx.n_layers)
+
+
 class _GrassmannDistance(torch.autograd.Function):
     """(selector, keys, teachers, *students) -> d_grass_sq (E, L), differentiable w.r.t. the student tokens
     (reference layer_selector.py:86-105; the backward is the eigenvector-perturbation route)."""
@@ -526,7 +550,8 @@ class BASDLoss(nn.Module):
             self._side_streams[key] = torch.cuda.Stream(device=device, priority=prio)
         return self._side_streams[key]
 
-    @torch.compiler.disable
+    # (no torch.compiler.disable wrapper: it costs ~40 us of host time per call on the step's critical path;
+    # under torch.compile the ctypes launches graph-break by themselves)
     def forward(
         self,
         student_output: torch.Tensor,
@@ -587,15 +612,8 @@ class BASDLoss(nn.Module):
             mix = sel.mixing_weights(students, keys, teachers)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), False, teachers, attns,
                                                  *students)
-        geo_loss = geo_layers.mean()
-
-        vals = [ce_loss, geo_loss]
-        # UW-SO weighting: w_i = (1/L_i) / sum_j (1/L_j), weights detached   (combined.py:78-85)
-        eps = torch.finfo(vals[0].dtype).eps
-        inv = torch.stack([1.0 / v.detach().clamp(min=eps) for v in vals])
-        w = inv / inv.sum()
+        total = _UWSOCombine.apply(ce_loss, geo_layers)
         self.last_components = {"ce": ce_loss.detach(), "geo_layers": geo_layers.detach(), "mix": mix.detach()}
-        total = sum(w[i] * vals[i] for i in range(len(vals)))
         ops.trace("combine_queued")
         if selector_tail is not None:
             selector_tail()
