@@ -581,8 +581,18 @@ __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restri
     const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     const float* p = partial + (long)blockIdx.y * parts * cols;
     float s = 0.f;
-    if (c < cols)
-        for (int k = pg; k < parts; k += 4) s += p[(long)k * cols + c];
+    if (c < cols) {
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four independent partial folds: loads overlap
+        int k = pg;
+        for (; k + 12 < parts; k += 16) {
+            s += p[(long)k * cols + c];
+            s1 += p[(long)(k + 4) * cols + c];
+            s2 += p[(long)(k + 8) * cols + c];
+            s3 += p[(long)(k + 12) * cols + c];
+        }
+        for (; k < parts; k += 4) s += p[(long)k * cols + c];
+        s = (s + s1) + (s2 + s3);
+    }
     red[pg][cl] = s;
     __syncthreads();
     if (pg == 0 && c < cols)
@@ -678,9 +688,11 @@ int basd_gemm_tn(const void* a, const void* b, int dtype, long a_sb, long a_sn, 
 }
 
 int basd_colmean_parts(int rows) {
-    int p = rows / 128;
+    // enough row slices to fill the chip (x column blocks x matrices), few enough that the second stage's
+    // serial fold stays short
+    int p = rows / 256;
     if (p < 1) p = 1;
-    if (p > 256) p = 256;
+    if (p > 64) p = 64;
     return p;
 }
 
