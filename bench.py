@@ -30,6 +30,7 @@ from basd_amd import _lib, ddp, ops, synth
 from basd_amd.losses import BASDLoss
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
 STUDENT_PARAMS = {"cfg1": 5_700_000, "cfg2": 22_050_664, "cfg4": 86_600_000, "cfg5": 86_600_000}
 LABEL_SMOOTHING = {"cfg1": 0.01, "cfg2": 0.001, "cfg4": 0.001, "cfg5": 0.001}
 
@@ -45,6 +46,17 @@ def algorithmic_bytes(shape: synth.LossShape, batch: int, elem: int = 4) -> dict
     fwd = student + teacher + attn
     grad = e * batch * shape.n_s * shape.d_s * 4
     return {"fwd": fwd, "bwd": fwd + grad, "step": 2 * fwd + grad, "student": student, "student_grad": grad}
+
+
+def measured_traffic(cfg: str) -> dict:
+    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/r01_traffic.json,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE); {} when not collected."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(cfg, {})
+    except (OSError, ValueError):
+        return {}
 
 
 def build(shape: synth.LossShape, cfg: str, device):
@@ -142,7 +154,7 @@ def main() -> None:
     # entry point basd_tridiag is exactly one launch).  HIP events are recorded on the stream it is queued on.
     dominant = "basd_tridiag" if ops.EIG_SOLVER == "tridiag" else "basd_jacobi_onesided"
     _lib.timing = {}
-    _lib.timed_names = None if args.breakdown else {dominant}
+    _lib.timed_names = None if args.breakdown else {dominant, "basd_syrk_multi"}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,7 +193,9 @@ def main() -> None:
             launches = 1
             n_mats = shape.points
             kernel_name = "tridiag_kernel (Householder tridiagonalisation of the E student Gram matrices)"
-            note = "per-CU L2 latency/issue bound: one workgroup per matrix, 383 dependent steps (DESIGN.md section 5)"
+            note = ("latency bound, not a stream: D_s - 1 dependent Householder steps, each an L2 round trip plus a "
+                    "tagged-granule hand-off between the workgroups sharing a matrix (DESIGN.md section 5); the "
+                    "roofline-bound kernel of the path is reported under roofline_mfma")
         else:
             nblk = ((d_s + 15) // 16 + 1) // 2 * 2
             launches = ops.MAX_SWEEPS * (nblk - 1)
@@ -194,6 +208,15 @@ def main() -> None:
         launch_ms = eig_ms / launches
         launch_bytes = solve_bytes / launches
         achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        traffic = measured_traffic(args.config)
+        # the MFMA-bound kernel of the path: symmetric Gram of the E student token matrices (one launch + its
+        # slab reduction per step; the teacher-side call of the same entry point is the shorter of the two)
+        tiles = (d_s + 127) // 128
+        syrk = sorted(per_call.get("basd_syrk_multi", [0.0]))
+        syrk = syrk[-args.steps:] if len(syrk) >= args.steps else syrk
+        syrk_ms = sum(syrk) / max(1, len(syrk))
+        syrk_flops = shape.points * (tiles * (tiles + 1) // 2) * 128 * 128 * 2.0 * batch * shape.n_s
+        syrk_tf = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         line = {
             "metric": "distillation images/sec (BASD loss fwd+bwd+grad all-reduce), DeiT-S<-ResNet-50 @ bs256/GPU"
             if args.config == "cfg2" else f"distillation images/sec (BASD loss), {shape.name}",
@@ -227,10 +250,19 @@ def main() -> None:
             "roofline": {
                 "kernel": kernel_name,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("tridiag_kernel"),
                 "launch_ms": launch_ms, "launches_per_step": launches, "solve_ms_per_step": eig_ms,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "note": note,
+            },
+            "roofline_mfma": {
+                "kernel": "syrk_tn_kernel (+ syrk_reduce_kernel): centred Gram matrices of the E student layers",
+                "bound": "mfma", "achieved": syrk_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                "frac": syrk_tf / MFMA_F32_PEAK_TF, "traffic": traffic.get("syrk_tn_kernel"),
+                "launch_ms": syrk_ms, "executed_flops_per_launch": syrk_flops,
+                "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32); flops counted are the lower-triangular 128x128 tile "
+                        "pairs actually executed; timed inside the step, i.e. while the teacher chain's kernels "
+                        "share the chip",
             },
         }
         if not args.no_cpu_baseline and world == 1:

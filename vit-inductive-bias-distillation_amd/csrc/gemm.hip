@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmOperand A, GemmOperand
 
 // ---------------------------------------------------------------------------
 // Multi-matrix symmetric TN (centred Gram / SYRK):  G[z] = scale[z] * (X_z - 1 mean_z^T)^T (X_z - 1 mean_z^T)
-//   grid = (T(T+1)/2 lower-triangular 128x128 tile pairs, splits, n_mats), block = 256.
+//   grid = T(T+1)/2 lower-triangular 128x128 tile pairs x splits x n_mats (1-D, decoded XCD-aware), block = 256.
 //   X_z share shape and strides, base pointers come from a device table.  Only tiles (mi >= ni) are
 //   computed; a diagonal tile stages its column slab once and feeds both MFMA operands from it.  Half the
 //   column-slab traffic of the general TN kernel (9 instead of 18 slab reads at 384 columns).
@@ -397,17 +397,33 @@ __device__ __forceinline__ void tri_tile(int p, int& mi, int& ni) {
 
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) syrk_tn_kernel(const void* const* __restrict__ ptrs, GemmOperand X, int cols,
-                                                      int Krows, int splits, const float* __restrict__ means,
-                                                      float* __restrict__ slabs) {
+                                                      int Krows, int splits, int n_mats, int pairs,
+                                                      const float* __restrict__ means, float* __restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float lds[2 * TN_BK * 128];
+    // XCD-aware decode of the 1-D grid: workgroup ids that agree mod 8 run on one XCD (one L2).  The tile
+    // pairs of one (matrix, split) unit read the same rows, so they are given ids of one residue class and
+    // adjacent dispatch slots: the unit's rows come over the fabric once, the other pairs hit in that L2
+    // (measured: 975 MB -> see profiles/ per launch at cfg-2 against 308 MB of operands).
+    int pair, unit;
+    {
+        const int units = splits * n_mats, id = blockIdx.x;
+        if ((units & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3;
+            pair = slot % pairs;
+            unit = xcd + 8 * (slot / pairs);
+        } else {
+            pair = id % pairs;
+            unit = id / pairs;
+        }
+    }
     int tmi, tni;
-    tri_tile(blockIdx.x, tmi, tni);
+    tri_tile(pair, tmi, tni);
     const bool diag = tmi == tni;
     float* tA = lds;
     float* tB = diag ? lds : lds + TN_BK * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = tmi * BM, n0 = tni * BN;
-    const int z = blockIdx.z, sp = blockIdx.y;
+    const int z = unit / splits, sp = unit - z * splits;
     X.ptr = ptrs[z];
     const float* mean = means ? means + (long)z * cols : nullptr;
     float* C = slabs + ((long)z * splits + sp) * (long)cols * cols;
@@ -748,14 +764,14 @@ int basd_syrk_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long
     BASD_CHECK_ARG(out_stride >= (long)cols * cols);
     GemmOperand X{nullptr, sb, sn, sd, rows_per_batch, 0};
     const int tiles = (cols + BM - 1) / BM, pairs = tiles * (tiles + 1) / 2;
-    const dim3 grid(pairs, splits, n_mats);
+    const dim3 grid(pairs * splits * n_mats);
     if (dtype == BASD_DTYPE_F32) {
         const bool vec = vec_ok && sd == 1 && sb % 4 == 0 && sn % 4 == 0;
-        if (vec) syrk_tn_kernel<float, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, means, slabs);
-        else syrk_tn_kernel<float, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, means, slabs);
+        if (vec) syrk_tn_kernel<float, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs);
+        else syrk_tn_kernel<float, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs);
     } else if (dtype == BASD_DTYPE_BF16) {
-        if (sd == 1) syrk_tn_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, means, slabs);
-        else syrk_tn_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, means, slabs);
+        if (sd == 1) syrk_tn_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs);
+        else syrk_tn_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs);
     } else {
         return BASD_EINVAL;
     }
