@@ -545,8 +545,10 @@ class BASDLoss(nn.Module):
     def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
         key = (str(device), index)
         if key not in self._side_streams:
-            # the eigen-solve chains (0, 1) are the step's critical path: high priority; the tail (2) is not
-            prio = -1 if index < 2 and os.environ.get("BASD_CHAIN_PRIORITY", "1") == "1" else 0
+            # the teacher chain (0) gates the step's one host read-back (the ranks): high priority, so that its
+            # kernels are dispatched ahead of the student chain's (1) and the main stream's when they compete
+            mode = os.environ.get("BASD_CHAIN_PRIORITY", "2")
+            prio = -1 if (mode == "1" and index < 2) or (mode == "2" and index == 0) else 0
             self._side_streams[key] = torch.cuda.Stream(device=device, priority=prio)
         return self._side_streams[key]
 
