@@ -125,27 +125,42 @@ def colmean(x: torch.Tensor) -> torch.Tensor:
     return mean
 
 
-def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None,
-                   scales: list[float] | None = None, out: torch.Tensor | None = None,
-                   splits: int | None = None) -> tuple[torch.Tensor, torch.Tensor]:
-    """Gram matrices of same-layout (B,N,D) / (M,D) views in two launches (+ reductions):
-    out[z] = scales[z] * (X_z - 1 mu_z^T)^T (X_z - 1 mu_z^T), mu_z the column means (0 where not centred).
-    Returns (out (n, D, D), means (n, D))."""
+def _gram_layout(xs: list[torch.Tensor]):
     _require_cuda(*xs)
-    n = len(xs)
     ptr, dt, sb, sn, sd, rpb = _tok3(xs[0])
     for x in xs[1:]:
         assert _tok3(x)[1:] == (dt, sb, sn, sd, rpb) and x.shape == xs[0].shape, "Gram operands must share a layout"
-    dev = xs[0].device
     rows = xs[0].shape[0] * xs[0].shape[1] if xs[0].dim() == 3 else xs[0].shape[0]
-    cols = xs[0].shape[-1]
+    vec_ok = int(all(x.data_ptr() % 16 == 0 for x in xs))
+    return (dt, sb, sn, sd, rpb), rows, xs[0].shape[-1], vec_ok
+
+
+def column_means(xs: list[torch.Tensor]) -> torch.Tensor:
+    """Column means of same-layout (B,N,D) / (M,D) views in one launch (+ fold) -> (n, D) fp32."""
+    (dt, sb, sn, sd, rpb), rows, cols, vec_ok = _gram_layout(xs)
+    n, dev = len(xs), xs[0].device
     table = _ptr_table(xs)
     means = torch.empty((n, cols), device=dev, dtype=torch.float32)
     parts = _lib.query("basd_colmean_parts", rows)
     partial = torch.empty((n, parts, cols), device=dev, dtype=torch.float32)
-    vec_ok = int(all(x.data_ptr() % 16 == 0 for x in xs))
     _lib.call("basd_colmean_multi", table.data_ptr(), dt, sb, sn, sd, rpb, rows, cols, n, parts, partial.data_ptr(),
               means.data_ptr(), vec_ok, _stream())
+    return means
+
+
+def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None,
+                   scales: list[float] | None = None, out: torch.Tensor | None = None,
+                   splits: int | None = None, means: torch.Tensor | None = None
+                   ) -> tuple[torch.Tensor, torch.Tensor]:
+    """Gram matrices of same-layout (B,N,D) / (M,D) views in two launches (+ reductions):
+    out[z] = scales[z] * (X_z - 1 mu_z^T)^T (X_z - 1 mu_z^T), mu_z the column means (0 where not centred).
+    ``means``: column means already queued by ``column_means`` (lets the caller put other work between the two
+    stages).  Returns (out (n, D, D), means (n, D))."""
+    (dt, sb, sn, sd, rpb), rows, cols, vec_ok = _gram_layout(xs)
+    n, dev = len(xs), xs[0].device
+    table = _ptr_table(xs)
+    if means is None:
+        means = column_means(xs)
     if centered is not None and not all(centered):
         keep = _device_consts(tuple(1.0 if c else 0.0 for c in centered), torch.float32, dev)
         means_used = means * keep.unsqueeze(1)
