@@ -39,11 +39,14 @@ typedef struct ihipStream_t* hipStream_t;
  *           `features @ features.T / M`           layer_selector.py:15;
  *           `U_s.T @ U_t`                          layer_selector.py:99.
  * A element (m, k): a + z*a_batch_stride + (m / a_rows_per_batch)*a_sb + (m % a_rows_per_batch)*a_sn + k*a_sd
- * (so (B, N, D) token views, CLS-sliced or channel-major, are consumed in place). B: fp32 row-major. */
+ * (so (B, N, D) token views, CLS-sliced or channel-major, are consumed in place). B: fp32 row-major.
+ * colsum_part (nullable, needs beta == 0): batch * ceil(M/128) * N floats; the kernel's epilogue leaves the column
+ * sums of every 128-row tile of C there.  col_mean (nullable, needs colsum_part): batch * N floats, the column means
+ * of C folded from those -- `z.mean(dim=0)` of layer_selector.py:35 without another pass over z. */
 int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, int a_rows_per_batch,
                  long a_batch_stride, const float* b, long ldb, long b_batch_stride, int M, int N, int K, int batch,
                  float* c, long ldc, long c_batch_stride, float scale, const float* bias, float beta,
-                 hipStream_t stream);
+                 float* colsum_part, float* col_mean, hipStream_t stream);
 
 /* Suggested split count over the contraction rows for basd_gemm_tn. */
 int basd_gemm_tn_splits(int krows);

@@ -39,6 +39,27 @@ def test_gemm_nt_layouts(dev):
     assert _rel(ops.gemm_nt(big, wb, scale=0.5), 0.5 * big.double() @ wb.double().T) < 2e-6
 
 
+@pytest.mark.parametrize("M,K,N,cm", [(1000, 96, 200, False), (12544 // 4, 2048 // 4, 384, True), (77, 40, 64, False)])
+def test_gemm_nt_column_mean_epilogue(dev, M, K, N, cm):
+    """Column means of C from the projection kernel's epilogue (ragged last row tile, channel-major A, bias)."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    if cm:    # channel-major teacher view (B, K, n) -> (B, n, K)
+        a = (torch.randn(M // 49, K, 49, generator=g) + 0.3).to(dev).transpose(1, 2)
+    else:
+        a = (torch.randn(M, K, generator=g) + 0.3).to(dev)
+    b = torch.randn(N, K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    out, mean = ops.gemm_nt(a, b, scale=0.5, bias=bias, col_mean=True)
+    ref = 0.5 * a.double().reshape(-1, K) @ b.double().T - bias.double()
+    assert _rel(out, ref) < 2e-6
+    assert _rel(mean, ref.mean(0)) < 2e-6
+    slot = torch.zeros(3, N, device=dev)
+    ops.gemm_nt(a, b, col_mean=True, mean_out=slot[1])
+    assert _rel(slot[1], (a.double().reshape(-1, K) @ b.double().T).mean(0)) < 2e-6
+    assert float(slot[0].abs().max()) == 0.0 and float(slot[2].abs().max()) == 0.0
+
+
 def test_gemm_tn_and_colmean(dev):
     from basd_amd import ops
     g = torch.Generator().manual_seed(2)

@@ -17,7 +17,7 @@ vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 # name -> argtypes (return type is always int)
 SIGNATURES = {
     "basd_gemm_nt": [vp, i32, i64, i64, i64, i32, i64, vp, i64, i64, i32, i32, i32, i32, vp, i64, i64, f32, vp, f32,
-                     vp],
+                     vp, vp, vp],
     "basd_gemm_tn_splits": [i32],
     "basd_gemm_tn": [vp, vp, i32, i64, i64, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp,
                      vp, i64, i64, f32, vp],

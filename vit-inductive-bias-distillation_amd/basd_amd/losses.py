@@ -268,8 +268,18 @@ class GrassmannianLayerSelector(nn.Module):
 
     # ---- teacher side: ranks + subspaces -------------------------------------------------
     @torch.no_grad()
-    def _teacher_projection(self, t: torch.Tensor) -> torch.Tensor:
-        return ops.gemm_nt(ops.as_supported(t), self.proj_t.float().contiguous())   # (M, d_s)  layer_selector.py:72 / :135
+    def _teacher_projections(self, teachers: list[torch.Tensor]) -> tuple[list[torch.Tensor], torch.Tensor]:
+        """Per teacher layer z = tokens @ proj_t^T (M, d_s)   (layer_selector.py:72 / :135), plus the mean rows the
+        Gram launch wants: [0 (uncentred Gram) x L, column means of z (:35) x L] when M >= d_s, else the means
+        alone.  The means come out of the projection kernel's epilogue."""
+        d_s, L = self.student_dim, len(teachers)
+        M = teachers[0].shape[0] * teachers[0].shape[1]
+        off = L if M >= d_s else 0
+        means = torch.zeros((off + L, d_s), device=teachers[0].device, dtype=torch.float32)
+        proj_t = self.proj_t.float().contiguous()
+        zs = [ops.gemm_nt(ops.as_supported(t), proj_t, col_mean=True, mean_out=means[off + l])[0]
+              for l, t in enumerate(teachers)]
+        return zs, means
 
     def _teacher_grams(self, teachers: list[torch.Tensor], projected: list[torch.Tensor] | None = None):
         """Per teacher layer: projected tokens -> uncentred Gram / M (for the MP rank, layer_selector.py:12-15)
@@ -280,18 +290,16 @@ class GrassmannianLayerSelector(nn.Module):
         M = B * n_t
         proj_t = self.proj_t.float().contiguous()
         n_u = d_s if M >= d_s else M
-        zs = [projected[l] if projected is not None else self._teacher_projection(t)
-              for l, t in enumerate(teachers)]
+        zs, means = projected if projected is not None else self._teacher_projections(teachers)
         if n_u == d_s:
             # uncentred / M and centred Grams of every layer's projected tokens: one symmetric launch,
             # laid out [uncentred 0..L-1, centred 0..L-1]
-            stack, _ = ops.centered_grams(zs + zs, centered=[False] * L + [True] * L,
-                                          scales=[1.0 / M] * L + [1.0] * L)
+            stack, _ = ops.centered_grams(zs + zs, scales=[1.0 / M] * L + [1.0] * L, means=means)
             return stack[:L], stack[L:], M, stack
         g_u = torch.empty((L, n_u, n_u), device=proj_t.device, dtype=torch.float32)
         for l, z in enumerate(zs):
             g_u[l] = _uncentred_gram(z)
-        g_c, _ = ops.centered_grams(zs)
+        g_c, _ = ops.centered_grams(zs, means=means)
         return g_u, g_c, M, None
 
     @torch.no_grad()
@@ -340,7 +348,7 @@ class GrassmannianLayerSelector(nn.Module):
             student_stream.wait_stream(cur)
             # two chains: give the teacher stream its first (large) launch before the host queues the
             # student chain, so both start together
-            projected = [self._teacher_projection(t) for t in teachers]
+            projected = self._teacher_projections(teachers)
         with torch.cuda.stream(student_stream if student_stream is not None else cur):
             # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
             # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)

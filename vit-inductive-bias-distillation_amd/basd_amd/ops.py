@@ -74,9 +74,11 @@ def _tok3(x: torch.Tensor) -> tuple[int, int, int, int, int, int]:
 # --------------------------------------------------------------------------- #
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, scale: float = 1.0, out: torch.Tensor | None = None,
             a_batch_stride: int = 0, b_batch_stride: int = 0, batch: int = 1, rows: int | None = None,
-            n_cols: int | None = None, bias: torch.Tensor | None = None, beta: float = 0.0) -> torch.Tensor:
+            n_cols: int | None = None, bias: torch.Tensor | None = None, beta: float = 0.0,
+            col_mean: bool = False, mean_out: torch.Tensor | None = None):
     """C = beta * C + scale * A @ B.T - bias.  A: (B,N,K) or (M,K) view in fp32/bf16; B: (N,K) fp32 row-major.
-    With batch > 1, element z uses a/b advanced by the given batch strides."""
+    With batch > 1, element z uses a/b advanced by the given batch strides.  ``col_mean``: also return the column
+    means of C (from the kernel's epilogue; no second pass over C) -> (C, means (batch?, N))."""
     _require_cuda(a, b)
     ptr, dt, sb, sn, sd, rpb = _tok3(a)
     M = rows if rows is not None else (a.shape[0] * a.shape[1] if a.dim() == 3 else a.shape[0])
@@ -86,9 +88,15 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, scale: float = 1.0, out: torch.
     ldb = b.stride(-2)
     if out is None:
         out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=a.device, dtype=torch.float32)
+    part = mean = None
+    if col_mean:
+        part = torch.empty((batch, (M + 127) // 128, N), device=a.device, dtype=torch.float32)
+        mean = mean_out if mean_out is not None else \
+            torch.empty((batch, N) if batch > 1 else (N,), device=a.device, dtype=torch.float32)
+        assert mean.dtype == torch.float32 and mean.is_contiguous() and mean.numel() == batch * N
     _lib.call("basd_gemm_nt", ptr, dt, sb, sn, sd, rpb, a_batch_stride, b.data_ptr(), ldb, b_batch_stride,
-              M, N, K, batch, out.data_ptr(), N, M * N, scale, _ptr(bias), beta, _stream())
-    return out
+              M, N, K, batch, out.data_ptr(), N, M * N, scale, _ptr(bias), beta, _ptr(part), _ptr(mean), _stream())
+    return (out, mean) if col_mean else out
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, mean_a: torch.Tensor | None = None,

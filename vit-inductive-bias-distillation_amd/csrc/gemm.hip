@@ -148,7 +148,8 @@ __device__ __forceinline__ void nt_store_lds(float* __restrict__ tile, int tid, 
 template <typename TA, bool VEC_A>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand B, int M, int N, int K,
                                                       float* __restrict__ C, long ldc, long c_batch_stride,
-                                                      float scale, const float* __restrict__ bias, float beta) {
+                                                      float scale, const float* __restrict__ bias, float beta,
+                                                      float* __restrict__ colsum_part) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 128 * NT_LD];
     float* tA = lds;
     float* tB = lds + 128 * NT_LD;
@@ -201,6 +202,33 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand
         }
     }
     store_tile(C, ldc, M, N, m0, n0, acc, wm, wn, lane, scale, bias, beta);
+    if (colsum_part) {
+        // column sums of this row tile of C (the values just stored; beta == 0): the caller's column means
+        // then cost one small fold instead of another pass over C.  Fixed order: deterministic.
+        const int col_l = lane & 31, hi = lane >> 5;
+        float s[2] = {0.f, 0.f};
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + col_l;
+            const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < M) s[ni] += acc[mi][ni][r] * scale - bv;
+                }
+            s[ni] += __shfl_xor(s[ni], 32, 64);      // the two lane halves hold different rows of one column
+        }
+        __syncthreads();                             // the K loop is done with the LDS tiles
+        if (hi == 0) {
+            lds[wm * 128 + wn * 64 + col_l] = s[0];
+            lds[wm * 128 + wn * 64 + 32 + col_l] = s[1];
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N)
+            colsum_part[((long)blockIdx.z * gridDim.y + blockIdx.y) * N + n0 + tid] = lds[tid] + lds[128 + tid];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -638,22 +666,26 @@ extern "C" {
 int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, int a_rows_per_batch,
                  long a_batch_stride, const float* b, long ldb, long b_batch_stride, int M, int N, int K, int batch,
                  float* c, long ldc, long c_batch_stride, float scale, const float* bias, float beta,
-                 hipStream_t stream) {
+                 float* colsum_part, float* col_mean, hipStream_t stream) {
     BASD_CHECK_ARG(a && b && c && M > 0 && N > 0 && K > 0 && batch > 0 && a_rows_per_batch > 0);
     BASD_CHECK_ARG(aligned16(b) && ldb % 4 == 0 && b_batch_stride % 4 == 0);
+    BASD_CHECK_ARG(!colsum_part || beta == 0.f);
+    BASD_CHECK_ARG(!col_mean || colsum_part);
     GemmOperand A{a, a_sb, a_sn, a_sd, a_rows_per_batch, a_batch_stride};
     GemmOperand B{b, 0, ldb, 1, 1 << 30, b_batch_stride};
     const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     if (a_dtype == BASD_DTYPE_F32) {
         const bool vec = a_sd == 1 && aligned16(a) && a_sb % 4 == 0 && a_sn % 4 == 0 && a_batch_stride % 4 == 0;
-        if (vec) gemm_nt_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta);
-        else gemm_nt_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta);
+        if (vec) gemm_nt_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part);
+        else gemm_nt_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part);
     } else if (a_dtype == BASD_DTYPE_BF16) {
-        if (a_sd == 1) gemm_nt_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta);
-        else gemm_nt_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta);
+        if (a_sd == 1) gemm_nt_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part);
+        else gemm_nt_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part);
     } else {
         return BASD_EINVAL;
     }
+    if (col_mean)      // fold the row-tile sums: col_mean[z][n] = (1/M) sum over the row tiles
+        colsum_final_kernel<<<dim3((N + 63) / 64, batch), 256, 0, stream>>>(colsum_part, N, (M + BM - 1) / BM, 1.f / M, col_mean);
     BASD_RETURN_LAST();
 }
 
