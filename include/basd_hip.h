@@ -117,8 +117,9 @@ int basd_sort_extract(const float* W, long batch_stride, int rows, int rows_tot,
 long basd_tridiag_workspace_bytes(int n, int batch);
 
 /* `work`: basd_tridiag_workspace_bytes(n, batch) bytes of 16-byte aligned device scratch.  A matrix is shared by
- * up to 8 workgroups that exchange one 16-byte granule per row and step through it; its last 16 bytes hold an
- * error word that is non-zero afterwards if a workgroup gave up waiting for its partners. */
+ * up to 8 workgroups that exchange one 16-byte granule per row and step through it; its last 32 bytes hold a
+ * status word that is non-zero afterwards if a workgroup gave up waiting for its partners, and a trace of the
+ * first give-up (step + 1, row, member | matrix << 8, tag seen, tag wanted). */
 int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
                  void* work, hipStream_t stream);
 

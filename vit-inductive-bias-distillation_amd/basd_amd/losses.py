@@ -394,9 +394,9 @@ class GrassmannianLayerSelector(nn.Module):
         host = torch.cat([ranks_dev.to(torch.int32), *errs]).tolist() if errs else ranks_dev.tolist()
         ops.trace("ranks_read")
         ranks = [int(r) for r in host[:L]]
-        if any(host[L:]):
+        if any(host[L::8]):
             raise RuntimeError("basd_tridiag: workgroups sharing a matrix timed out waiting for each other "
-                               "(device oversubscribed?); eigen-solve results are invalid")
+                               f"(device oversubscribed?); eigen-solve results are invalid [status words {host[L:]}]")
         for k, r in zip(keys, ranks):
             self.subspace_ranks[k] = r
         if min(ranks) == 0:

@@ -225,7 +225,8 @@ class TridiagState:
     tau: torch.Tensor
     vh: torch.Tensor
     vals: torch.Tensor      # (batch, n) descending
-    err: torch.Tensor | None = None   # (1,) int32, non-zero if the workgroups sharing a matrix lost each other
+    err: torch.Tensor | None = None   # (8,) int32; [0] non-zero if the workgroups sharing a matrix lost each other
+                                      # ([1:6] then: step + 1, row, member | matrix << 8, tag seen, tag wanted)
 
 
 def tridiag_eigenvalues(G: torch.Tensor) -> TridiagState:
@@ -242,7 +243,7 @@ def tridiag_eigenvalues(G: torch.Tensor) -> TridiagState:
     _lib.call("basd_tridiag", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
               vh.data_ptr(), work.data_ptr(), st)
     _lib.call("basd_tridiag_eigenvalues", d.data_ptr(), e.data_ptr(), n, batch, vals.data_ptr(), st)
-    return TridiagState(d, e, tau, vh, vals, work[-16:-12].view(torch.int32))
+    return TridiagState(d, e, tau, vh, vals, work[-32:].view(torch.int32))
 
 
 def tridiag_eigenvectors(ts: TridiagState, k: int, first: int = 0, count: int | None = None) -> torch.Tensor:

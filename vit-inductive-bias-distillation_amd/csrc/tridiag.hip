@@ -14,6 +14,7 @@
 // vector lives in LDS.  Everything is fp32, like LAPACK's ssytd2 / sstebz / sstein it restates.
 #include "basd_common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace basd {
 
@@ -38,20 +39,25 @@ __device__ __forceinline__ float block_sum_lds(float v, float* scratch, int nw) 
 }
 
 // ---- hand-off of per-row results between the workgroups that share one matrix -----------------
-// One 16-byte granule per matrix row and step parity: (p_r, captured column entry, step tag, 0), written
-// and polled with sc1 accesses (served by L2 / fabric, never by a CU's L1).  The tag travels with the data,
-// so there is no separate flag, fence or atomic on the dependent chain: a consumer simply re-reads the
-// granule until it carries the tag of the current step.  Two parities suffice: a workgroup can only be one
+// One 16-byte granule per matrix row and step parity: (p_r, captured column entry, tag, 0), written and polled
+// with sc1 accesses (served by L2 / fabric, never by a CU's L1; coherent across XCDs).  The tag travels with
+// the data, so there is no separate flag, fence or atomic on the dependent chain: a consumer simply re-reads
+// the granule until it carries the tag of the current step.  Two parities suffice: a workgroup can only be one
 // step ahead of the slowest one (it needs that one's granules of the step in between).
+// tag = (launch nonce << 12) | step: granules left behind by an earlier launch in a recycled buffer never match,
+// so the buffer needs no clearing (and no fill kernel's cached lines can land on top of a published granule).
+typedef unsigned tri_u32x4 __attribute__((ext_vector_type(4)));
 typedef float tri_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void granule_store(float4* p, float4 v) {
-    const tri_f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+__device__ __forceinline__ void granule_store(uint4* p, float a, float b, unsigned tag) {
+    const tri_u32x4 x = {__float_as_uint(a), __float_as_uint(b), tag, 0u};
+    // the trailing s_nop covers the >8-byte store's data-register hazard: hipcc pads nothing after inline asm,
+    // and its next instruction may otherwise overwrite x before the store has read it
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
-__device__ __forceinline__ float4 granule_load(const float4* p) {
-    tri_f32x4 x;
+__device__ __forceinline__ tri_u32x4 granule_load(const uint4* p) {
+    tri_u32x4 x;
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
-    return make_float4(x.x, x.y, x.z, x.w);
+    return x;
 }
 
 // Eight row chunks in flight, then one wait: hipcc's schedulers otherwise sink each load next to its first
@@ -93,8 +99,8 @@ template <bool VEC, bool FULL>
 __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, long a_batch_stride, int n, int batch,
                                                        int batch_pad, int P, float* __restrict__ d,
                                                        float* __restrict__ e, float* __restrict__ tau_out,
-                                                       float* __restrict__ Vh, float4* __restrict__ xg,
-                                                       int* __restrict__ err) {
+                                                       float* __restrict__ Vh, uint4* __restrict__ xg,
+                                                       int* __restrict__ err, unsigned tag_base, int lag_member) {
     // ONE pass over the trailing block per step: the rank-2 update of step j-1 is applied lazily while the
     // rows are read for the matrix-vector product of step j (a' = a - v_r w_c - w_r v_c ; p_r += a' u_c), and
     // the column the next reflector is built from is captured on the way.  All vectors are indexed by ABSOLUTE
@@ -118,18 +124,25 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
     float* ez = e + (long)z * n;
     float* tz = tau_out + (long)z * n;
     float* Vz = Vh + (long)z * n * n;
-    float4* xz = xg + (long)z * 2 * n;
+    uint4* xz = xg + (long)z * 2 * n;
     constexpr int RB = TRI_RB;
     const int nblk = (n + TRI_BLK - 1) / TRI_BLK;
     int budget = 1 << 22;      // polls before a member gives up on its partners (never reached when all are resident)
+    if (blockIdx.x == 0 && threadIdx.x < 8) __hip_atomic_store(err + threadIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int r = tid; r < n; r += nthr) {
         v[r] = 0.f;
         w[r] = 0.f;
         col[r] = Az[(long)r * n];
     }
     __syncthreads();
+    // my last block: once the active rows have passed it I hold no live row, nobody reads my granules any more
+    // and nobody would wait for me either (the lock-step below is among members with live rows) -- so leave.
+    const int my_last_blk = ((nblk - 1 - p) / P) * P + p;
+    const int last_owner = (nblk - 1) % P;           // owns row n-1: alive to the end
     for (int j = 0; j < n - 1; ++j) {
         const int r0 = j + 1;
+        if (r0 / TRI_BLK > my_last_blk) break;       // uniform over the workgroup
+        if (p == lag_member) __builtin_amdgcn_s_sleep(127);      // test hook: one member falls behind every step
         float part = 0.f;
         for (int r = r0 + 1 + tid; r < n; r += nthr) part = fmaf(col[r], col[r], part);
         const float xn2 = block_sum_lds(part, red, nw);
@@ -140,13 +153,14 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
             beta = -copysignf(sqrtf(fmaf(alpha, alpha, xn2)), alpha);
             tau = (beta - alpha) / beta;
         }
-        if (p == 0 && tid == 0) {
+        // outputs of the step are written by the member that owns row r0 (it has live rows, hence is in step)
+        const bool writes_v = p == (r0 / TRI_BLK) % P;
+        if (writes_v && tid == 0) {
             dz[j] = col[j];
             ez[j] = beta;
             tz[j] = tau;
         }
         const float scal = tau != 0.f ? 1.f / (alpha - beta) : 0.f;
-        const bool writes_v = p == j % P;     // reflector rows for the back-transformation: members take turns
         for (int r = tid; r < n; r += nthr) {
             const float ur = r < r0 ? 0.f : (r == r0 ? 1.f : col[r] * scal);
             u[r] = ur;
@@ -231,26 +245,33 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         lds_barrier();
         const int coff = r0 - c_begin;      // position of column r0 inside the captured chunk
         if (P > 1) {
-            float4* xp = xz + (long)(j & 1) * n;
-            const float tag = __int_as_float(j);
+            uint4* xp = xz + (long)(j & 1) * n;
+            const unsigned tag = tag_base | (unsigned)j;
             // publish my live blocks: wave (local block % nw), lanes 0..31 -> 512 contiguous bytes per store
             if (lane < TRI_BLK) {
                 for (int lb = lb0 + wave; lb * P + p < nblk; lb += nw) {
                     const int r = (lb * P + p) * TRI_BLK + lane;
-                    if (r < n) granule_store(xp + r, make_float4(pw[r], cap4[4 * r + coff], tag, 0.f));
+                    if (r < n) granule_store(xp + r, pw[r], cap4[4 * r + coff], tag);
                 }
             }
             // collect the other members' rows
             for (int r = b_first * TRI_BLK + tid; r < n; r += nthr) {
                 if ((r / TRI_BLK) % P == p) continue;
-                float4 g = granule_load(xp + r);
-                while (__float_as_int(g.z) != j && budget > 0) {
+                tri_u32x4 g = granule_load(xp + r);
+                while (g.z != tag && budget > 0) {
                     __builtin_amdgcn_s_sleep(1);
                     --budget;
                     g = granule_load(xp + r);
                 }
-                pw[r] = g.x;
-                cap4[4 * r + coff] = g.y;
+                if (g.z != tag && err[1] == 0) {      // first give-up of the launch: leave a trace for the host
+                    err[1] = j + 1;
+                    err[2] = r;
+                    err[3] = p | (z << 8);
+                    err[4] = (int)g.z;
+                    err[5] = (int)tag;
+                }
+                pw[r] = __uint_as_float(g.x);
+                cap4[4 * r + coff] = __uint_as_float(g.y);
             }
             lds_barrier();
         }
@@ -271,8 +292,8 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         lds_barrier();
     }
     __syncthreads();
-    if (budget <= 0) *err = 1;
-    if (p == 0) {
+    if (budget <= 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == last_owner) {
         if (tid == 0) {
             dz[n - 1] = col[n - 1];
             ez[n - 1] = 0.f;
@@ -621,8 +642,8 @@ static int tridiag_members(int n, int batch) {
 }
 
 long basd_tridiag_workspace_bytes(int n, int batch) {
-    // per matrix: 2 parities x n granules of 16 bytes; plus one error word (padded to 16 bytes)
-    return (long)batch * 2 * n * 16 + 16;
+    // per matrix: 2 parities x n granules of 16 bytes; plus the status word and 7 words of give-up trace
+    return (long)batch * 2 * n * 16 + 32;
 }
 
 int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
@@ -632,21 +653,24 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
     if (n > 4096) return BASD_EUNSUPPORTED;
     const bool vec = (n & 3) == 0 && (a_batch_stride & 3) == 0 && (((uintptr_t)a) & 15) == 0;
     const int P = tridiag_members(n, batch);
-    const int batch_pad = P > 1 ? (batch + 7) & ~7 : batch;
+    int batch_pad = P > 1 ? (batch + 7) & ~7 : batch;
+    if (const char* s = getenv("BASD_TRIDIAG_PAD")) batch_pad = batch + atoi(s);     // experiment: scatter members over XCDs
     const long gran_bytes = (long)batch * 2 * n * 16;
-    float4* xg = (float4*)work;
+    uint4* xg = (uint4*)work;
     int* err = (int*)((char*)work + gran_bytes);
-    // tags start at -1 (no step); error word at 0
-    if (hipMemsetAsync(work, 0xFF, gran_bytes, stream) != hipSuccess) return BASD_EINVAL;
-    if (hipMemsetAsync(err, 0, 16, stream) != hipSuccess) return BASD_EINVAL;
+    // 20-bit launch nonce in the granule tags (12 bits of step below it: n <= 4096)
+    static std::atomic<unsigned> launches{0};
+    const unsigned tag_base = ((launches.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xFFFFFu) << 12;
     const size_t lds = sizeof(float) * 9 * (size_t)n;
+    int lag = -1;                                   // BASD_TRIDIAG_LAG=<member>: test hook, see tridiag_kernel
+    if (const char* s = getenv("BASD_TRIDIAG_LAG")) lag = atoi(s);
     // a member with one 32-row block keeps only four waves busy in the pass: fewer waves make the barriers
     // cheaper (n = 384, 12 members: 1.63 ms with 1024 threads, 1.55 with 512, 1.66 with 256)
     int threads = (P > 1 && (nblk_of(n) + P - 1) / P <= 1) ? 512 : 1024;
     if (const char* s = getenv("BASD_TRIDIAG_THREADS")) threads = atoi(s);
-    if (vec && (n & 7) == 0) tridiag_kernel<true, true><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
-    else if (vec) tridiag_kernel<true, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
-    else tridiag_kernel<false, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err);
+    if (vec && (n & 7) == 0) tridiag_kernel<true, true><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag);
+    else if (vec) tridiag_kernel<true, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag);
+    else tridiag_kernel<false, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag);
     BASD_RETURN_LAST();
 }
 
