@@ -28,9 +28,10 @@ namespace basd {
 // wave (static row ownership below), whose own accesses to an address are served in issue order.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// One barrier: every call site owns its scratch slots, and between two uses of a slot array all threads pass
+// at least one other workgroup barrier (so nobody can still be reading the previous round's partials).
 __device__ __forceinline__ float block_sum_lds(float v, float* scratch, int nw) {
     v = wave_sum(v);
-    lds_barrier();
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     lds_barrier();
     float r = 0.f;
@@ -139,21 +140,19 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
     // and nobody would wait for me either (the lock-step below is among members with live rows) -- so leave.
     const int my_last_blk = ((nblk - 1 - p) / P) * P + p;
     const int last_owner = (nblk - 1) % P;           // owns row n-1: alive to the end
-    for (int j = 0; j < n - 1; ++j) {
+    // Reflector of step j from column j of the current matrix (col[], rows >= j): every thread forms tau / beta
+    // itself (same inputs everywhere: no broadcast); the member that owns row j+1 -- it has live rows at step j,
+    // hence is in step -- writes d_j, e_j, tau_j and the reflector row.  `xn2` = sum_{r > j+1} col[r]^2.
+    float tau = 0.f;
+    auto form_reflector = [&](int j, float xn2) {
         const int r0 = j + 1;
-        if (r0 / TRI_BLK > my_last_blk) break;       // uniform over the workgroup
-        if (p == lag_member) __builtin_amdgcn_s_sleep(127);      // test hook: one member falls behind every step
-        float part = 0.f;
-        for (int r = r0 + 1 + tid; r < n; r += nthr) part = fmaf(col[r], col[r], part);
-        const float xn2 = block_sum_lds(part, red, nw);
         const float alpha = col[r0];
-        // every thread forms tau / beta itself (same inputs everywhere): no broadcast, no extra barrier
-        float tau = 0.f, beta = alpha;
+        float beta = alpha;
+        tau = 0.f;
         if (xn2 > 0.f) {
             beta = -copysignf(sqrtf(fmaf(alpha, alpha, xn2)), alpha);
             tau = (beta - alpha) / beta;
         }
-        // outputs of the step are written by the member that owns row r0 (it has live rows, hence is in step)
         const bool writes_v = p == (r0 / TRI_BLK) % P;
         if (writes_v && tid == 0) {
             dz[j] = col[j];
@@ -167,6 +166,16 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
             if (writes_v) Vz[(long)j * n + r] = ur;
         }
         lds_barrier();
+    };
+    {
+        float part = 0.f;
+        for (int r = 2 + tid; r < n; r += nthr) part = fmaf(col[r], col[r], part);
+        form_reflector(0, block_sum_lds(part, red, nw));
+    }
+    for (int j = 0; j < n - 1; ++j) {
+        const int r0 = j + 1;
+        if (r0 / TRI_BLK > my_last_blk) break;       // uniform over the workgroup
+        if (p == lag_member) __builtin_amdgcn_s_sleep(127);      // test hook: one member falls behind every step
         const int c_begin = VEC ? (r0 & ~3) : r0;
         // my live row groups: local group lg -> block (lg / 4) * P + p, group lg % 4 of it; wave lg % nw owns it
         const int b_first = r0 / TRI_BLK;
@@ -277,19 +286,27 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         }
         float gp = 0.f;
         for (int r = r0 + tid; r < n; r += nthr) gp = fmaf(pw[r], u[r], gp);
-        const float gamma = -0.5f * tau * block_sum_lds(gp, red, nw);
-        const float w0 = fmaf(gamma, u[r0], pw[r0]);
-        lds_barrier();                                   // everybody has read pw[r0] before it is rewritten
-        // w_j = p + gamma u; column r0 of the matrix with update j applied; (u, w_j) become the pending update
+        const float pw0 = pw[r0];                        // read before anything below rewrites LDS
+        const float gamma = -0.5f * tau * block_sum_lds(gp, red + 16, nw);
+        const float w0 = fmaf(gamma, 1.f, pw0);          // u[r0] = 1
+        // w_j = p + gamma u; column r0 of the matrix with update j applied -- the column the NEXT reflector is
+        // built from, so its norm is accumulated here and the reflector of step j+1 is formed right away (one
+        // block reduction and one loop per step less than forming it at the top of the step); (u, w_j) become the
+        // pending update
+        float part = 0.f;
         for (int r = tid; r < n; r += nthr) {
             const float ur = u[r];
             const float wn = r >= r0 ? fmaf(gamma, ur, pw[r]) : 0.f;
-            if (r >= r0) col[r] = cap4[4 * r + coff] - fmaf(ur, w0, wn);     // u[r0] = 1
+            if (r >= r0) {
+                const float cn = cap4[4 * r + coff] - fmaf(ur, w0, wn);
+                col[r] = cn;
+                if (r > r0 + 1) part = fmaf(cn, cn, part);
+            }
             v[r] = ur;
             w[r] = wn;
-            pw[r] = wn;
         }
-        lds_barrier();
+        const float xn2 = block_sum_lds(part, red, nw);   // its barrier also publishes col[] / v[] / w[]
+        if (j + 1 < n - 1) form_reflector(j + 1, xn2);
     }
     __syncthreads();
     if (budget <= 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
