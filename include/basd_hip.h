@@ -126,6 +126,15 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
 /* All eigenvalues (descending) of the tridiagonals by Sturm-sequence bisection. */
 int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, float* vals_desc, hipStream_t stream);
 
+/* Marchenko-Pastur rank of each tridiagonal without its spectrum: the lower median eigenvalue by 1025-section
+ * Sturm counts, the threshold median * factor rounded to fp32, and one Sturm count at the threshold
+ * (layer_selector.py:16-19; `factor` = (1 + sqrt(D/M))^2 in float64 from the host, `cap` as :74).
+ * This is the quantity the host reads back every step: host_mirror (nullable) is device-visible pinned host memory
+ * of batch + 8 ints; the kernel writes the ranks and the 8 words at `status` (nullable: the status area of
+ * basd_tridiag's workspace) straight into it. */
+int basd_tridiag_mp_rank(const float* d, const float* e, int n, int batch, double factor, int cap, int* rank_out,
+                         float* thr_out, const int* status, int* host_mirror, hipStream_t stream);
+
 /* Leading k eigenvectors of the original matrices (inverse iteration on T, cluster re-orthogonalisation,
  * back-transformation with the reflectors), written as rows of vecs (batch, k_stride, n).
  * z: batch*k*n floats of scratch. */

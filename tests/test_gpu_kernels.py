@@ -293,3 +293,26 @@ def test_tridiag_eigensolver(dev, n, k):
     p = vecs[:, :kk].transpose(1, 2) @ vecs[:, :kk]
     pr = ref_vecs[:, :, :kk] @ ref_vecs[:, :, :kk].transpose(1, 2)
     assert (p - pr).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("n,M", [(384, 12544), (192, 2048), (100, 300), (33, 64)])
+def test_tridiag_mp_rank_matches_full_spectrum(dev, n, M):
+    """basd_tridiag_mp_rank (median by multisection + one Sturm count) against the rank computed from the complete
+    bisection spectrum, and against fp64 eigvalsh."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(n)
+    out = []
+    mats = []
+    for r in (3, 17, n // 3):
+        x = torch.randn(M, r, generator=g) @ torch.randn(r, n, generator=g) * (4.0 / r ** 0.5) + torch.randn(M, n, generator=g)
+        mats.append(x.T @ x / M)
+    G0 = torch.stack(mats).to(dev)
+    ts = ops.tridiag_eigenvalues(G0.clone())
+    fast = ops.tridiag_mp_rank(ts, M, n, cap=n - 1).cpu()
+    full = ops.mp_rank_device(ts.vals, M, n, cap=n - 1).cpu()
+    assert torch.equal(fast, full), (fast, full)
+    ev = torch.linalg.eigvalsh(G0.double().cpu())
+    lam = ev[:, (n - 1) // 2] * (1 + (n / M) ** 0.5) ** 2
+    ref = (ev > lam.unsqueeze(1)).sum(1).clamp(max=n - 1).to(torch.int32)
+    assert torch.equal(fast, ref), (fast, ref)
+    assert int(fast.min()) >= 1

@@ -110,7 +110,8 @@ def _align_token_count(tokens: torch.Tensor, target_n: int) -> torch.Tensor:
 def _record_stream(obj, stream) -> None:
     """Mark every tensor reachable from a (nested) state object as in use on `stream`."""
     if isinstance(obj, torch.Tensor):
-        obj.record_stream(stream)
+        if obj.is_cuda:
+            obj.record_stream(stream)
     elif isinstance(obj, dict):
         for v in obj.values():
             _record_stream(v, stream)
@@ -358,7 +359,13 @@ class GrassmannianLayerSelector(nn.Module):
             if stud_jacobi:
                 st["s_stack"], st["s_colnorm"] = s_stack, ops.jacobi_onesided(s_stack, d_s)
             else:
-                st["s_ts"] = ops.tridiag_eigenvalues(s_stack)
+                s_ts = ops.tridiagonalise(s_stack)
+                if student_stream is not None:
+                    # status word of this factorisation: read by the host one step later (it never waits for
+                    # the student chain)
+                    st["student_status"] = self._queue_readback([s_ts.err], "student")
+                ops.tridiag_spectrum(s_ts)
+                st["s_ts"] = s_ts
 
         # ---- teacher side: projection, Grams, eigen-solve, MP ranks ----
         g_u, g_c, M, t_stack = self._teacher_grams(teachers, projected)
@@ -367,10 +374,24 @@ class GrassmannianLayerSelector(nn.Module):
         if not same:
             t_stack = g_c
         st["o_c"] = o_c
+        if tri and same:
+            # The host waits for the ranks and for nothing else: they come straight from the tridiagonals of
+            # the uncentred Grams (median by multisection + one Sturm count), are copied to pinned memory at
+            # once, and only then are the centred spectra (needed by the eigenvector stage alone) queued.
+            ts = ops.tridiagonalise(t_stack)
+            st["t_ts"] = ts
+            pin = self._pinned_ints("teacher", L + 8)
+            st["ranks_dev"] = ops.tridiag_mp_rank(ts, M, d_s, cap=d_s - 1, first=0, count=L,
+                                                  host_mirror=pin)                              # :16-19, :74
+            ready = torch.cuda.Event()
+            ready.record()
+            st["rank_ready"] = (pin, ready)
+            ops.tridiag_spectrum(ts, first=o_c, count=L)
+            return st
         if tri:
             ts = ops.tridiag_eigenvalues(t_stack)
             st["t_ts"] = ts
-            vals_u = ts.vals[:L] if same else ops.tridiag_eigenvalues(g_u).vals
+            vals_u = ops.tridiag_eigenvalues(g_u).vals
         else:
             colnorm = ops.jacobi_onesided(t_stack, d_s)
             st["t_stack"], st["t_colnorm"] = t_stack, colnorm
@@ -381,6 +402,28 @@ class GrassmannianLayerSelector(nn.Module):
         st["ranks_dev"] = ops.mp_rank_device(vals_u, M, d_s, cap=d_s - 1)    # :74
         return st
 
+    def _pinned_ints(self, slot: str, count: int) -> torch.Tensor:
+        """Pinned int32 host buffer; two per slot, used alternately, so that a value may still be read one step
+        later while the next step's is being produced."""
+        bufs = self.__dict__.setdefault("_pinned", {})
+        flip = self.__dict__.setdefault("_pinned_flip", {})
+        idx = flip.get(slot, 0)
+        flip[slot] = idx ^ 1
+        key = (slot, idx)
+        if key not in bufs or bufs[key].numel() != count:
+            bufs[key] = torch.empty((count,), dtype=torch.int32, pin_memory=True)
+        return bufs[key]
+
+    def _queue_readback(self, tensors: list[torch.Tensor], slot: str):
+        """Async copy of small int32 device tensors into a pinned buffer on the current stream + an event."""
+        pin, off = self._pinned_ints(slot, sum(t.numel() for t in tensors)), 0
+        for t in tensors:
+            pin[off:off + t.numel()].copy_(t.reshape(-1), non_blocking=True)
+            off += t.numel()
+        ev = torch.cuda.Event()
+        ev.record()
+        return pin, ev
+
     @torch.no_grad()
     def _angles_from_spectra(self, st: dict, keys: list[int], want_grad: bool = False):
         """The step's single D2H read-back (ranks), then principal angles -> d_grass_sq (E, L)
@@ -390,13 +433,26 @@ class GrassmannianLayerSelector(nn.Module):
         ranks_dev, o_c, E, L = (st[k] for k in ("ranks_dev", "o_c", "E", "L"))
         dev = ranks_dev.device
         # the step's one read-back: the ranks, and behind them the status words of the eigen-solves
-        errs = [st[k].err for k in ("t_ts", "s_ts") if k in st and st[k].err is not None]
-        host = torch.cat([ranks_dev.to(torch.int32), *errs]).tolist() if errs else ranks_dev.tolist()
+        if "rank_ready" in st:
+            pin, ev = st["rank_ready"]
+            ev.synchronize()                       # the teacher chain up to the rank kernel; nothing else
+            host = pin.tolist()
+            status = host[L:L + 1]
+            pending = self.__dict__.pop("_pending_status", None)
+            if pending is not None:                # student chain of the PREVIOUS step: long complete
+                pending[1].synchronize()
+                status.append(int(pending[0][0]))
+            if "student_status" in st:
+                self._pending_status = st["student_status"]
+        else:
+            errs = [st[k].err for k in ("t_ts", "s_ts") if k in st and st[k].err is not None]
+            host = torch.cat([ranks_dev.to(torch.int32), *errs]).tolist() if errs else ranks_dev.tolist()
+            status = host[L::8]
         ops.trace("ranks_read")
         ranks = [int(r) for r in host[:L]]
-        if any(host[L::8]):
+        if any(status):
             raise RuntimeError("basd_tridiag: workgroups sharing a matrix timed out waiting for each other "
-                               f"(device oversubscribed?); eigen-solve results are invalid [status words {host[L:]}]")
+                               f"(device oversubscribed?); eigen-solve results are invalid [{host[L:]}]")
         for k, r in zip(keys, ranks):
             self.subspace_ranks[k] = r
         if min(ranks) == 0:

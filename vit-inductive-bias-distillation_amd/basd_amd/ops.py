@@ -229,8 +229,9 @@ class TridiagState:
                                       # ([1:6] then: step + 1, row, member | matrix << 8, tag seen, tag wanted)
 
 
-def tridiag_eigenvalues(G: torch.Tensor) -> TridiagState:
-    """G (batch, n, n) symmetric, DESTROYED.  Queues tridiagonalisation + Sturm bisection; no host sync."""
+def tridiagonalise(G: torch.Tensor) -> TridiagState:
+    """G (batch, n, n) symmetric, DESTROYED.  Queues the Householder tridiagonalisation; ``vals`` is allocated but
+    not filled (``tridiag_spectrum``).  No host sync."""
     _require_cuda(G)
     assert G.dtype == torch.float32 and G.is_contiguous() and G.dim() == 3 and G.shape[1] == G.shape[2]
     batch, n, _ = G.shape
@@ -238,12 +239,43 @@ def tridiag_eigenvalues(G: torch.Tensor) -> TridiagState:
     d, e, tau = (torch.empty((batch, n), **f32) for _ in range(3))
     vh = torch.empty((batch, n, n), **f32)
     vals = torch.empty((batch, n), **f32)
-    st = _stream()
     work = torch.empty((_lib.query("basd_tridiag_workspace_bytes", n, batch),), device=G.device, dtype=torch.uint8)
     _lib.call("basd_tridiag", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
-              vh.data_ptr(), work.data_ptr(), st)
-    _lib.call("basd_tridiag_eigenvalues", d.data_ptr(), e.data_ptr(), n, batch, vals.data_ptr(), st)
+              vh.data_ptr(), work.data_ptr(), _stream())
     return TridiagState(d, e, tau, vh, vals, work[-32:].view(torch.int32))
+
+
+def tridiag_spectrum(ts: TridiagState, first: int = 0, count: int | None = None) -> torch.Tensor:
+    """All eigenvalues (descending) of matrices [first, first + count) by Sturm bisection -> view of ``ts.vals``."""
+    batch, n = ts.vals.shape
+    count = batch - first if count is None else count
+    _lib.call("basd_tridiag_eigenvalues", ts.d[first].data_ptr(), ts.e[first].data_ptr(), n, count,
+              ts.vals[first].data_ptr(), _stream())
+    return ts.vals[first:first + count]
+
+
+def tridiag_mp_rank(ts: TridiagState, M: int, D: int, cap: int, first: int = 0, count: int | None = None,
+                    host_mirror: torch.Tensor | None = None) -> torch.Tensor:
+    """Marchenko-Pastur ranks (int32, device) of matrices [first, first + count) straight from the tridiagonals
+    (median by multisection + one Sturm count at the threshold; the spectra are not computed).
+    ``host_mirror``: pinned int32 host tensor of count + 8 elements that the kernel fills with the ranks and the
+    factorisation's status words (read it after an event recorded behind this call)."""
+    batch, n = ts.vals.shape
+    count = batch - first if count is None else count
+    factor = (1 + (D / M) ** 0.5) ** 2          # float64 on the host, as reference layer_selector.py:11,18
+    out = torch.empty((count,), device=ts.d.device, dtype=torch.int32)
+    if host_mirror is not None:
+        assert host_mirror.is_pinned() and host_mirror.dtype == torch.int32 and host_mirror.numel() == count + 8
+    _lib.call("basd_tridiag_mp_rank", ts.d[first].data_ptr(), ts.e[first].data_ptr(), n, count, factor, cap,
+              out.data_ptr(), None, _ptr(ts.err) if host_mirror is not None else None, _ptr(host_mirror), _stream())
+    return out
+
+
+def tridiag_eigenvalues(G: torch.Tensor) -> TridiagState:
+    """G (batch, n, n) symmetric, DESTROYED.  Queues tridiagonalisation + Sturm bisection; no host sync."""
+    ts = tridiagonalise(G)
+    tridiag_spectrum(ts)
+    return ts
 
 
 def tridiag_eigenvectors(ts: TridiagState, k: int, first: int = 0, count: int | None = None) -> torch.Tensor:

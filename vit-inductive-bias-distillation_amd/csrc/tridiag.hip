@@ -635,6 +635,102 @@ __global__ void __launch_bounds__(256) backtransform_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Marchenko-Pastur rank straight from the tridiagonal (reference layer_selector.py:16-19): the rank needs the
+// lower median eigenvalue and the number of eigenvalues above median * factor -- two order statistics, not the
+// spectrum.  One workgroup of 1024 threads per matrix: 1025-section for the median (every thread runs one Sturm
+// count per pass: three or four passes instead of the full bisection of all n eigenvalues), then ONE Sturm count
+// at the threshold.  This is what the host waits for each step; the full spectrum is only needed later, for
+// the eigenvectors.  Same arithmetic as sturm_bisect_kernel / mp_rank_kernel (pivmin rule, convergence rule,
+// threshold rounded to fp32); "eigenvalue > threshold" is counted as n - #(eigenvalues < threshold).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int sturm_count(const float* dd, const float* e2, int n, float x, float pivmin) {
+    int cnt = 0;
+    float q = dd[0] - x;
+    if (fabsf(q) < pivmin) q = -pivmin;
+    cnt += q < 0.f;
+    for (int r = 1; r < n; ++r) {
+        q = (dd[r] - x) - e2[r - 1] * __builtin_amdgcn_rcpf(q);
+        if (fabsf(q) < pivmin) q = -pivmin;
+        cnt += q < 0.f;
+    }
+    return cnt;
+}
+
+__global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __restrict__ d, const float* __restrict__ e,
+                                                               int n, double factor, int cap,
+                                                               int* __restrict__ rank_out, float* __restrict__ thr_out,
+                                                               const int* __restrict__ status,
+                                                               int* __restrict__ host_mirror) {
+    extern __shared__ float sm[];
+    float* dd = sm;        // n
+    float* e2 = sm + n;    // n
+    __shared__ float red3[3][16];
+    const int z = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
+    const float* dz = d + (long)z * n;
+    const float* ez = e + (long)z * n;
+    float lo = 3.4e38f, hi = -3.4e38f, emax = 0.f;
+    for (int i = tid; i < n; i += nthr) {
+        const float di = dz[i];
+        const float el = i > 0 ? fabsf(ez[i - 1]) : 0.f, er = i < n - 1 ? fabsf(ez[i]) : 0.f;
+        dd[i] = di;
+        e2[i] = i < n - 1 ? ez[i] * ez[i] : 0.f;
+        lo = fminf(lo, di - el - er);
+        hi = fmaxf(hi, di + el + er);
+        emax = fmaxf(emax, er * er);
+    }
+    lo = -wave_max(-lo);
+    hi = wave_max(hi);
+    emax = wave_max(emax);
+    __syncthreads();
+    if ((tid & 63) == 0) { red3[0][tid >> 6] = lo; red3[1][tid >> 6] = hi; red3[2][tid >> 6] = emax; }
+    __syncthreads();
+    for (int i = 0; i < nwv; ++i) {
+        lo = fminf(lo, red3[0][i]);
+        hi = fmaxf(hi, red3[1][i]);
+        emax = fmaxf(emax, red3[2][i]);
+    }
+    const float tnorm = fmaxf(fabsf(lo), fabsf(hi));
+    const float eps = 1.1920929e-7f;
+    lo -= 2.f * tnorm * eps * n + 1e-37f;
+    hi += 2.f * tnorm * eps * n + 1e-37f;
+    const float pivmin = fmaxf(1.1754944e-38f * fmaxf(emax, 1.f), 1e-37f);
+
+    const int k_asc = (n - 1) / 2;                        // lower median, as torch.median
+    float a = lo, b = hi;
+    for (int it = 0; it < 40; ++it) {
+        const float x = a + (b - a) * ((float)(tid + 1) / (float)(nthr + 1));
+        const bool below = sturm_count(dd, e2, n, x, pivmin) <= k_asc;
+        // new bracket: the largest point with count <= k and the smallest with count > k
+        float na = wave_max(below && x > a ? x : a);
+        float nb = wave_max(-((!below && x < b) ? x : b));
+        __syncthreads();                                   // previous round's readers are done with red3
+        if ((tid & 63) == 0) { red3[0][tid >> 6] = na; red3[1][tid >> 6] = nb; }
+        __syncthreads();
+        for (int i = 0; i < nwv; ++i) {
+            na = fmaxf(na, red3[0][i]);
+            nb = fmaxf(nb, red3[1][i]);
+        }
+        nb = -nb;
+        const bool stalled = !(na > a) && !(nb < b);      // points collapsed onto the ends: resolution reached
+        a = na;
+        b = nb;
+        if (stalled || b - a <= 2.f * eps * fmaxf(fabsf(a), fabsf(b)) + pivmin) break;   // uniform
+    }
+    const float sigma2 = 0.5f * (a + b);
+    const float lam = (float)((double)sigma2 * factor);
+    if (tid == 0) {
+        const int above = n - sturm_count(dd, e2, n, lam, pivmin);
+        rank_out[z] = above < cap ? above : cap;
+        if (thr_out) thr_out[z] = lam;
+        // the host's copy, written straight into pinned memory (no copy engine round on the critical path):
+        // [ranks x batch, 8 status words of the factorisation]
+        if (host_mirror) host_mirror[z] = above < cap ? above : cap;
+    }
+    if (host_mirror && status && z == 0 && tid < 8) host_mirror[gridDim.x + tid] = status[tid];
+}
+
 }  // namespace basd
 
 using namespace basd;
@@ -696,6 +792,17 @@ int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, f
     BASD_CHECK_ARG(d && e && vals_desc && n > 0 && batch > 0);
     if (n > 8192) return BASD_EUNSUPPORTED;
     sturm_bisect_kernel<<<dim3((n + 63) / 64, batch), 1024, sizeof(float) * 2 * (size_t)n, stream>>>(d, e, n, vals_desc);
+    BASD_RETURN_LAST();
+}
+
+// MP ranks of `batch` tridiagonals (d, e: batch x n) without computing their spectra; `factor` = (1 + sqrt(D/M))^2
+// in float64 from the host as in basd_mp_rank.  thr_out nullable.  host_mirror (nullable): device-visible pinned
+// host memory of batch + 8 ints that receives the ranks and the 8 words at `status` (nullable).
+int basd_tridiag_mp_rank(const float* d, const float* e, int n, int batch, double factor, int cap, int* rank_out,
+                         float* thr_out, const int* status, int* host_mirror, hipStream_t stream) {
+    BASD_CHECK_ARG(d && e && rank_out && n > 0 && batch > 0);
+    if (n > 8192) return BASD_EUNSUPPORTED;
+    tridiag_mp_rank_kernel<<<batch, 1024, sizeof(float) * 2 * (size_t)n, stream>>>(d, e, n, factor, cap, rank_out, thr_out, status, host_mirror);
     BASD_RETURN_LAST();
 }
 
