@@ -106,6 +106,10 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
     // rows are read for the matrix-vector product of step j (a' = a - v_r w_c - w_r v_c ; p_r += a' u_c), and
     // the column the next reflector is built from is captured on the way.  All vectors are indexed by ABSOLUTE
     // row/column (zero below the active block), so the pass runs over 16-byte aligned column chunks.
+    // Latency-critical: a chain of dependent steps on few waves, usually sharing its SIMDs with throughput
+    // kernels of other streams (Gram MFMA loops, the Procrustes Jacobi).  Top wave priority makes the issue
+    // arbiter serve these waves first; the background kernels lose next to nothing.
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* v = sm;             // previous reflector
     float* w = sm + n;         // its w = p + gamma v
@@ -326,6 +330,30 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
 // every eigenvalue is owned by one DPP row of 16 lanes that evaluates 16 interior points of its bracket per
 // pass (17-section): ~8 passes instead of 45.  grid = (ceil(n/64), batch), block = 1024 = 64 eigenvalues x 16.
 // ---------------------------------------------------------------------------
+// Sturm count #(eigenvalues < x) of the tridiagonal (dz, ez); x may differ per lane, (dz, ez) is per wave.
+// The recurrence walks the diagonal in order and every lane reads the same element: dz / ez are wave-uniform
+// GLOBAL addresses, so the compiler fetches them with scalar loads (s_load_dwordx8 after unrolling) through the
+// constant cache -- no LDS traffic.  That matters because these kernels share their CUs with the LDS-bound
+// Procrustes Jacobi of the caller's stream: with the diagonal in LDS the rank kernel took 360 us inside a
+// training step (50 alone), with scalar loads 195.  (Tried and dropped: 64 entries per VGPR broadcast with
+// v_readlane -- the SGPR hazards make every step longer; 0.32 ms for the full bisection against 0.20.)
+__device__ __forceinline__ int sturm_count(const float* __restrict__ dz, const float* __restrict__ ez, int n, float x,
+                                           float pivmin) {
+    int cnt = 0;
+    float q = dz[0] - x;
+    if (fabsf(q) < pivmin) q = -pivmin;
+    cnt += q < 0.f;
+#pragma unroll 8
+    for (int r = 1; r < n; ++r) {
+        // 1-ulp hardware reciprocal: the count is only ambiguous where q is round-off anyway
+        const float er = ez[r - 1];
+        q = (dz[r] - x) - (er * er) * __builtin_amdgcn_rcpf(q);
+        if (fabsf(q) < pivmin) q = -pivmin;
+        cnt += q < 0.f;
+    }
+    return cnt;
+}
+
 __device__ __forceinline__ float row16_allmax(float x) {
     x = fmaxf(x, dpp_get<0xB1>(x));
     x = fmaxf(x, dpp_get<0x4E>(x));
@@ -336,9 +364,6 @@ __device__ __forceinline__ float row16_allmax(float x) {
 
 __global__ void __launch_bounds__(1024) sturm_bisect_kernel(const float* __restrict__ d, const float* __restrict__ e,
                                                             int n, float* __restrict__ vals_desc) {
-    extern __shared__ float sm[];
-    float* dd = sm;        // n
-    float* e2 = sm + n;    // n (e2[i] = e[i]^2, i < n-1)
     __shared__ float red3[3][16];
     const int z = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
     const float* dz = d + (long)z * n;
@@ -347,8 +372,6 @@ __global__ void __launch_bounds__(1024) sturm_bisect_kernel(const float* __restr
     for (int i = tid; i < n; i += nthr) {
         const float di = dz[i];
         const float el = i > 0 ? fabsf(ez[i - 1]) : 0.f, er = i < n - 1 ? fabsf(ez[i]) : 0.f;
-        dd[i] = di;
-        e2[i] = i < n - 1 ? ez[i] * ez[i] : 0.f;
         lo = fminf(lo, di - el - er);
         hi = fmaxf(hi, di + el + er);
         emax = fmaxf(emax, er * er);
@@ -375,27 +398,23 @@ __global__ void __launch_bounds__(1024) sturm_bisect_kernel(const float* __restr
     const bool live = i < n;
     const int k_asc = n - 1 - (live ? i : n - 1);         // 0-based ascending index
     float a = lo, b = hi;
+    bool done = false;                                    // uniform within a row of 16 lanes
     for (int it = 0; it < 40; ++it) {
-        // 16 interior points of [a, b]; every lane of the row runs one Sturm count
+        // 16 interior points of [a, b]; every lane of the row runs one Sturm count.  The whole wave stays in the
+        // loop until its four rows are done (sturm_count broadcasts across all 64 lanes); a finished row idles.
         const float x = a + (b - a) * ((float)(sub + 1) * (1.f / 17.f));
-        int cnt = 0;
-        float q = dd[0] - x;
-        if (fabsf(q) < pivmin) q = -pivmin;
-        cnt += q < 0.f;
-        for (int r = 1; r < n; ++r) {
-            // 1-ulp hardware reciprocal: the count is only ambiguous where q is round-off anyway
-            q = (dd[r] - x) - e2[r - 1] * __builtin_amdgcn_rcpf(q);
-            if (fabsf(q) < pivmin) q = -pivmin;
-            cnt += q < 0.f;
-        }
+        const int cnt = sturm_count(dz, ez, n, x, pivmin);
         // new bracket: the largest point with count <= k and the smallest with count > k
         const bool below = cnt <= k_asc;
         const float na = row16_allmax(below && x > a ? x : a);
         const float nb = -row16_allmax(-((!below && x < b) ? x : b));
-        const bool stalled = !(na > a) && !(nb < b);      // points collapsed onto the ends: resolution reached
-        a = na;
-        b = nb;
-        if (stalled || b - a <= 2.f * eps * fmaxf(fabsf(a), fabsf(b)) + pivmin) break;   // uniform within the row
+        if (!done) {
+            const bool stalled = !(na > a) && !(nb < b);  // points collapsed onto the ends: resolution reached
+            a = na;
+            b = nb;
+            done = stalled || b - a <= 2.f * eps * fmaxf(fabsf(a), fabsf(b)) + pivmin;
+        }
+        if (__all(done)) break;
     }
     if (live && sub == 0) vals_desc[(long)z * n + i] = 0.5f * (a + b);
 }
@@ -645,27 +664,12 @@ __global__ void __launch_bounds__(256) backtransform_kernel(const float* __restr
 // the eigenvectors.  Same arithmetic as sturm_bisect_kernel / mp_rank_kernel (pivmin rule, convergence rule,
 // threshold rounded to fp32); "eigenvalue > threshold" is counted as n - #(eigenvalues < threshold).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int sturm_count(const float* dd, const float* e2, int n, float x, float pivmin) {
-    int cnt = 0;
-    float q = dd[0] - x;
-    if (fabsf(q) < pivmin) q = -pivmin;
-    cnt += q < 0.f;
-    for (int r = 1; r < n; ++r) {
-        q = (dd[r] - x) - e2[r - 1] * __builtin_amdgcn_rcpf(q);
-        if (fabsf(q) < pivmin) q = -pivmin;
-        cnt += q < 0.f;
-    }
-    return cnt;
-}
-
 __global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __restrict__ d, const float* __restrict__ e,
                                                                int n, double factor, int cap,
                                                                int* __restrict__ rank_out, float* __restrict__ thr_out,
                                                                const int* __restrict__ status,
                                                                int* __restrict__ host_mirror) {
-    extern __shared__ float sm[];
-    float* dd = sm;        // n
-    float* e2 = sm + n;    // n
+    __builtin_amdgcn_s_setprio(3);     // the host is waiting for this kernel: see tridiag_kernel
     __shared__ float red3[3][16];
     const int z = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
     const float* dz = d + (long)z * n;
@@ -674,8 +678,6 @@ __global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __re
     for (int i = tid; i < n; i += nthr) {
         const float di = dz[i];
         const float el = i > 0 ? fabsf(ez[i - 1]) : 0.f, er = i < n - 1 ? fabsf(ez[i]) : 0.f;
-        dd[i] = di;
-        e2[i] = i < n - 1 ? ez[i] * ez[i] : 0.f;
         lo = fminf(lo, di - el - er);
         hi = fmaxf(hi, di + el + er);
         emax = fmaxf(emax, er * er);
@@ -701,7 +703,7 @@ __global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __re
     float a = lo, b = hi;
     for (int it = 0; it < 40; ++it) {
         const float x = a + (b - a) * ((float)(tid + 1) / (float)(nthr + 1));
-        const bool below = sturm_count(dd, e2, n, x, pivmin) <= k_asc;
+        const bool below = sturm_count(dz, ez, n, x, pivmin) <= k_asc;
         // new bracket: the largest point with count <= k and the smallest with count > k
         float na = wave_max(below && x > a ? x : a);
         float nb = wave_max(-((!below && x < b) ? x : b));
@@ -720,8 +722,8 @@ __global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __re
     }
     const float sigma2 = 0.5f * (a + b);
     const float lam = (float)((double)sigma2 * factor);
+    const int above = n - sturm_count(dz, ez, n, lam, pivmin);     // whole waves: the count broadcasts across lanes
     if (tid == 0) {
-        const int above = n - sturm_count(dd, e2, n, lam, pivmin);
         rank_out[z] = above < cap ? above : cap;
         if (thr_out) thr_out[z] = lam;
         // the host's copy, written straight into pinned memory (no copy engine round on the critical path):
@@ -791,7 +793,7 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
 int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, float* vals_desc, hipStream_t stream) {
     BASD_CHECK_ARG(d && e && vals_desc && n > 0 && batch > 0);
     if (n > 8192) return BASD_EUNSUPPORTED;
-    sturm_bisect_kernel<<<dim3((n + 63) / 64, batch), 1024, sizeof(float) * 2 * (size_t)n, stream>>>(d, e, n, vals_desc);
+    sturm_bisect_kernel<<<dim3((n + 63) / 64, batch), 1024, 0, stream>>>(d, e, n, vals_desc);
     BASD_RETURN_LAST();
 }
 
@@ -802,7 +804,7 @@ int basd_tridiag_mp_rank(const float* d, const float* e, int n, int batch, doubl
                          float* thr_out, const int* status, int* host_mirror, hipStream_t stream) {
     BASD_CHECK_ARG(d && e && rank_out && n > 0 && batch > 0);
     if (n > 8192) return BASD_EUNSUPPORTED;
-    tridiag_mp_rank_kernel<<<batch, 1024, sizeof(float) * 2 * (size_t)n, stream>>>(d, e, n, factor, cap, rank_out, thr_out, status, host_mirror);
+    tridiag_mp_rank_kernel<<<batch, 1024, 0, stream>>>(d, e, n, factor, cap, rank_out, thr_out, status, host_mirror);
     BASD_RETURN_LAST();
 }
 
