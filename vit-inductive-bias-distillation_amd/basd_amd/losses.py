@@ -424,14 +424,10 @@ class GrassmannianLayerSelector(nn.Module):
         ev.record()
         return pin, ev
 
-    @torch.no_grad()
-    def _angles_from_spectra(self, st: dict, keys: list[int], want_grad: bool = False):
-        """The step's single D2H read-back (ranks), then principal angles -> d_grass_sq (E, L)
-        (layer_selector.py:95-105).  Refreshes ``subspace_ranks``.  Returns (d, saved state for
-        ``_distance_backward`` or None)."""
-        d_s = self.student_dim
-        ranks_dev, o_c, E, L = (st[k] for k in ("ranks_dev", "o_c", "E", "L"))
-        dev = ranks_dev.device
+    def _read_ranks(self, st: dict, keys: list[int]) -> list[int]:
+        """The step's one host read-back: the MP ranks (and the status words of the eigen-solves).  Blocks on
+        the teacher chain's rank kernel only.  Refreshes ``subspace_ranks``; raises like the reference on rank 0."""
+        ranks_dev, L = st["ranks_dev"], st["L"]
         # the step's one read-back: the ranks, and behind them the status words of the eigen-solves
         if "rank_ready" in st:
             pin, ev = st["rank_ready"]
@@ -460,6 +456,18 @@ class GrassmannianLayerSelector(nn.Module):
             raise torch.linalg.LinAlgError(
                 "linalg.svd: The algorithm failed to converge because the input matrix contained "
                 "non-finite values (a teacher layer has Marchenko-Pastur rank 0).")
+        return ranks
+
+    @torch.no_grad()
+    def _angles_from_spectra(self, st: dict, keys: list[int], want_grad: bool = False,
+                             ranks_host: list[int] | None = None):
+        """The step's single D2H read-back (ranks), then principal angles -> d_grass_sq (E, L)
+        (layer_selector.py:95-105).  Refreshes ``subspace_ranks``.  Returns (d, saved state for
+        ``_distance_backward`` or None)."""
+        d_s = self.student_dim
+        ranks_dev, o_c, E, L = (st[k] for k in ("ranks_dev", "o_c", "E", "L"))
+        dev = ranks_dev.device
+        ranks = ranks_host if ranks_host is not None else self._read_ranks(st, keys)
         kmax = max(ranks)
         n_stud = d_s if want_grad else kmax
         # student eigenvectors (on the student chain's stream when there is one)
@@ -662,16 +670,25 @@ class BASDLoss(nn.Module):
             ops.trace("procrustes_queued")
 
             def selector_tail():
-                # eigenvectors + principal angles on a third stream: the next step's eigen-solve chains do not
-                # queue behind it.  The host reads the ranks here (and raises on rank 0 like the reference);
-                # called last so that everything else of the step is queued before the host blocks.
+                # The host reads the ranks here (and raises on rank 0 like the reference); called last so that
+                # everything else of the step is queued before the host blocks.  The rest of the selector
+                # (eigenvectors, principal angles) goes to a third stream: the next step's eigen-solve chains do
+                # not queue behind it, and nothing of it feeds this loss when there is one teacher layer.
+                # (Queuing it one call later, in the window where the host idles waiting for the ranks, was
+                # measured on the same box: the ranks then arrive 0.25 ms later and the step time is unchanged.)
+                if "rank_ready" in spectra:
+                    ranks = sel._read_ranks(spectra, keys)              # waits on the rank kernel's event
+                else:
+                    with torch.cuda.stream(side):                       # plain read-back behind both chains
+                        side.wait_stream(side2)
+                        ranks = sel._read_ranks(spectra, keys)
                 tail = self._selector_stream(main.device, 2)
                 tail.wait_stream(side)
                 tail.wait_stream(side2)
                 _record_stream(spectra, tail)
                 spectra["student_stream"] = None
                 with torch.cuda.stream(tail):
-                    sel._angles_from_spectra(spectra, keys)
+                    sel._angles_from_spectra(spectra, keys, ranks_host=ranks)
         else:
             selector_tail = None
             ce_loss = self.base_criterion(student_output, targets)
