@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 import make_goldens_shapes as S
-from basd_amd import synth
+from basd_amd import synth, ops, losses
 from oracle import basd_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -290,3 +290,17 @@ def test_selector_forward_api_materialises_mixed_tensors(golden):
         assert mixed[l].shape == inp.teacher[0].shape and mixed_attn[l].shape == inp.attn[0].shape
         np.testing.assert_allclose(mixed[l][:, :5, :7].cpu().numpy(), g[f"mixed_{l}_slice"], rtol=2e-3, atol=2e-4)
         np.testing.assert_allclose(mixed_attn[l][:, :, 0, 1:].cpu().numpy(), g[f"attn_{l}_cls_row"], rtol=2e-3, atol=1e-6)
+    # the reference's per-layer helper, driven the way the reference's forward drives it (layer_selector.py:131-150)
+    sel = mod.layer_selector
+    keys = sorted(inp.teacher)
+    sub, spw = {}, {}
+    with torch.no_grad():
+        for k in keys:
+            z_t = ops.gemm_nt(inp.teacher[k], sel.proj_t.float().contiguous())
+            sub[k], spw[k] = losses._grassmann_subspace(z_t, k=sel.subspace_ranks[k])
+        tok = torch.stack([inp.teacher[k] for k in keys])
+        att = torch.stack([inp.attn[k] for k in keys])
+        for i, l in enumerate(mod.token_layers):
+            m, a = sel._mix_for_student_layer(i, inp.student[l], keys, tok, att, sub, spw)
+            np.testing.assert_allclose(m[:, :5, :7].cpu().numpy(), g[f"mixed_{l}_slice"], rtol=2e-3, atol=2e-4)
+            np.testing.assert_allclose(a[:, :, 0, 1:].cpu().numpy(), g[f"attn_{l}_cls_row"], rtol=2e-3, atol=1e-6)

@@ -555,6 +555,50 @@ class GrassmannianLayerSelector(nn.Module):
         tau = self.temperatures.float()
         return torch.softmax(-d / tau.unsqueeze(1), dim=1)
 
+    @torch.no_grad()
+    def _mix_for_student_layer(
+        self,
+        i: int,
+        s_tokens: torch.Tensor,
+        teacher_indices: list[int],
+        stacked_tokens: torch.Tensor,
+        stacked_attns: torch.Tensor,
+        subspaces: dict[int, torch.Tensor],
+        spectral_weights: dict[int, torch.Tensor],
+    ) -> tuple[torch.Tensor, torch.Tensor]:
+        """API parity with reference layer_selector.py:76-114 (same arguments, same return): teacher layers mixed
+        for student layer ``i`` from PRE-COMPUTED teacher subspaces / spectral weights (``_grassmann_subspace``
+        outputs in the projected space) and ``self.subspace_ranks``.  Values only: the differentiable path of
+        the training loss is ``mixing_weights`` (which ``BASDLoss`` uses and which never materialises the mix)."""
+        d_s = self.student_dim
+        x = ops.as_supported(s_tokens)
+        kmax = max(int(self.subspace_ranks[t]) for t in teacher_indices)
+        if kmax < 1:
+            raise torch.linalg.LinAlgError(
+                "linalg.svd: The algorithm failed to converge because the input matrix contained "
+                "non-finite values (a teacher layer has Marchenko-Pastur rank 0).")
+        gram, _ = ops.centered_grams([x])                                     # :88-91 (proj_s folded below)
+        ts = ops.tridiag_eigenvalues(gram)
+        v_s = ops.tridiag_eigenvectors(ts, kmax)[0]                           # (kmax, d_s): Vt of the raw tokens
+        proj_s_t = self._proj_s_transposed()
+        L = len(teacher_indices)
+        cos = torch.zeros((L, kmax, kmax), device=x.device, dtype=torch.float32)
+        sw = torch.zeros((L, kmax), device=x.device, dtype=torch.float32)
+        for j, t_idx in enumerate(teacher_indices):
+            k = int(self.subspace_ranks[t_idx])
+            u_t = subspaces[t_idx].float()[:, :k]                             # (d_s, k) in the projected space
+            u_rot = ops.gemm_nt(u_t.t().contiguous(), proj_s_t)               # rows: (proj_s^T u)^T   (:99)
+            cos[j, :k, :k] = ops.gemm_nt(v_s[:k].contiguous(), u_rot)         # Vt_s[:k] proj_s^T U_t
+            sw[j, :k] = spectral_weights[t_idx].float()[:k]
+        k_arr = torch.tensor([int(self.subspace_ranks[t]) for t in teacher_indices], dtype=torch.int32).to(x.device)
+        sigma = ops.jacobi_onesided(cos, kmax, n_arr=k_arr)
+        sw_index = torch.arange(L, device=x.device, dtype=torch.int32)
+        d = ops.grassmann_distance(sigma, k_arr, sw, sw_index)                # :100-105
+        weights = torch.softmax(-d / self.temperatures[i].float(), dim=0).to(stacked_tokens.dtype)    # :107-110
+        mixed = (weights.view(-1, 1, 1, 1) * stacked_tokens).sum(dim=0)
+        mixed_attn = (weights.view(-1, 1, 1, 1, 1) * stacked_attns).sum(dim=0)
+        return mixed, mixed_attn
+
     def forward(
         self,
         student_tokens_per_layer: dict[int, torch.Tensor],
