@@ -75,6 +75,17 @@ def test_drop_in_module_paths():
     for name in ("GrassmannianLayerSelector", "marchenko_pastur_rank", "_grassmann_subspace"):
         assert hasattr(ls, name)
     assert hasattr(rel, "geometric_relational_loss") and hasattr(combined, "_align_token_count")
+    # every method of the reference classes exists under the same name with the same parameters
+    import inspect
+    sel = ls.GrassmannianLayerSelector
+    assert list(inspect.signature(sel._mix_for_student_layer).parameters) == [
+        "self", "i", "s_tokens", "teacher_indices", "stacked_tokens", "stacked_attns", "subspaces", "spectral_weights"]
+    assert list(inspect.signature(sel.forward).parameters) == [
+        "self", "student_tokens_per_layer", "all_teacher_tokens", "all_teacher_attns", "extraction_indices"]
+    assert list(inspect.signature(sel._estimate_ranks).parameters) == ["self", "all_teacher_tokens"]
+    assert list(inspect.signature(combined.BASDLoss.forward).parameters) == [
+        "self", "student_output", "targets", "student_intermediates", "all_teacher_tokens", "all_teacher_attns"]
+    assert isinstance(sel.temperatures, property)
 
 
 def test_interp_taps_match_oracle():
