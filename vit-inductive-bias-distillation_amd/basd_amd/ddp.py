@@ -37,11 +37,14 @@ class FlatGradBucket:
 
     def all_reduce_mean(self) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            if dist.get_backend() == "nccl":
-                dist.all_reduce(self.buffer, op=dist.ReduceOp.AVG)      # RCCL averages in the reduction
-            else:
-                dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM)      # gloo (CPU tests) has no AVG
-                self.buffer.div_(dist.get_world_size())
+            if dist.get_backend() == "nccl" and getattr(self, "_avg_ok", True):
+                try:
+                    dist.all_reduce(self.buffer, op=dist.ReduceOp.AVG)  # RCCL averages in the reduction
+                    return
+                except (RuntimeError, ValueError):                      # a build without ncclAvg: rejected before launch
+                    self._avg_ok = False
+            dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM)          # gloo (CPU tests) has no AVG
+            self.buffer.div_(dist.get_world_size())
 
     def unpack_loss_grads(self) -> None:
         off = self.student_numel
