@@ -126,6 +126,18 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
 /* All eigenvalues (descending) of the tridiagonals by Sturm-sequence bisection. */
 int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, float* vals_desc, hipStream_t stream);
 
+/* out (batch, k_stride, n) rows = Q x (transpose = 0) or Q^T x (transpose = 1) for the rows of x (batch, k, n), Q the
+ * product of the reflectors of basd_tridiag.  With basd_tridiag_shifted_solve this gives (A - lambda I)^{-1} on the
+ * orthogonal complement of the leading eigenvectors: the part of the backward of `torch.linalg.svd(...).Vh[:k]`
+ * (layer_selector.py:92 under autograd) that involves the eigenvectors NOT computed. */
+int basd_tridiag_apply_q(const float* tau, const float* vh, int n, int k, int batch, const float* x, float* out,
+                         int k_stride, int transpose, hipStream_t stream);
+
+/* x[z][t] = (T_z - shifts[z][t] I)^{-1} rhs[z][t], t < k: LU with partial pivoting + one solve with perturbed tiny
+ * pivots (shifts are eigenvalues; the caller projects the singular direction out).  rhs, x: (batch, k, n). */
+int basd_tridiag_shifted_solve(const float* d, const float* e, const float* shifts, int shift_stride, int n, int k,
+                               int batch, const float* rhs, float* x, hipStream_t stream);
+
 /* Marchenko-Pastur rank of each tridiagonal without its spectrum: the lower median eigenvalue by 1025-section
  * Sturm counts, the threshold median * factor rounded to fp32, and one Sturm count at the threshold
  * (layer_selector.py:16-19; `factor` = (1 + sqrt(D/M))^2 in float64 from the host, `cap` as :74).

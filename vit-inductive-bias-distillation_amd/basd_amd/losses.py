@@ -339,7 +339,9 @@ class GrassmannianLayerSelector(nn.Module):
         E, L = len(students), len(teachers)
         dev = students[0].device
         tri = ops.EIG_SOLVER == "tridiag"
-        stud_jacobi = all_student_vectors or not tri
+        # all student eigenvectors are only needed by the Jacobi-mode backward; the tridiagonal route's backward
+        # works from the leading k and shifted solves (``_distance_backward``)
+        stud_jacobi = not tri
         st = dict(E=E, L=L, tri=tri, stud_jacobi=stud_jacobi, student_stream=student_stream)
 
         # ---- student side: centred Grams -> eigen-solve ----
@@ -477,7 +479,6 @@ class GrassmannianLayerSelector(nn.Module):
             if st["stud_jacobi"]:
                 lam_s, v_all = ops.sort_extract(st["s_stack"], st["s_colnorm"], n_stud)
             else:
-                assert not want_grad
                 lam_s = st["s_ts"].vals
                 v_all = ops.tridiag_eigenvectors(st["s_ts"], kmax)
         # teacher eigenvectors
@@ -514,7 +515,7 @@ class GrassmannianLayerSelector(nn.Module):
         sigma = ops.jacobi_onesided(ang, kmax)
         d = ops.grassmann_distance(sigma, k_arr, sw, sw_index).view(E, L)
         saved = dict(ang=ang, sigma=sigma, k_arr=k_arr, sw=sw, sw_index=sw_index, u_rot=u_rot, v_all=v_all,
-                     lam=lam_s, means=st["means"], kmax=kmax, E=E, L=L)
+                     lam=lam_s, means=st["means"], kmax=kmax, E=E, L=L, s_ts=st.get("s_ts"))
         return d, saved
 
     @torch.no_grad()
@@ -526,23 +527,51 @@ class GrassmannianLayerSelector(nn.Module):
         gwt = ops.grassmann_distance_bwd(sv["ang"], sv["sigma"], sv["k_arr"], sv["sw"], sv["sw_index"],
                                          gd.reshape(E * L).float())                    # (E*L, kmax, kmax)
         u_flat = sv["u_rot"].view(L * kmax, d_s)
-        m_all = torch.empty((E, d_s, kmax), device=gd.device, dtype=torch.float32)
-        for e in range(E):
-            # G_V^T (kmax x d_s) = sum_l gW_l U_l'^T : contraction over (l, j)
-            gvt = ops.gemm_tn(gwt[e * L:(e + 1) * L].view(L * kmax, kmax), u_flat)
-            m_all[e] = ops.gemm_nt(sv["v_all"][e], gvt)                                 # M = V^T G_V  (d_s x kmax)
-        k2 = ops.eigvec_k2(m_all, sv["lam"])                                            # (E, d_s, d_s), symmetric
+        # G_V^T (kmax x d_s) per student layer = sum_l gW_l U_l'^T : contraction over (l, j)
+        gvt = torch.stack([ops.gemm_tn(gwt[e * L:(e + 1) * L].view(L * kmax, kmax), u_flat) for e in range(E)])
+        if sv.get("s_ts") is not None:
+            qs = self._eigvec_adjoint_leading(sv, gvt)
+        else:
+            m_all = torch.empty((E, d_s, kmax), device=gd.device, dtype=torch.float32)
+            for e in range(E):
+                m_all[e] = ops.gemm_nt(sv["v_all"][e], gvt[e])                          # M = V^T G_V  (d_s x kmax)
+            k2 = ops.eigvec_k2(m_all, sv["lam"])                                        # (E, d_s, d_s), symmetric
+            qs = []
+            for e in range(E):
+                v = sv["v_all"][e]
+                qs.append(ops.gemm_tn(v, ops.gemm_tn(k2[e], v)))                        # Q = V K2 V^T (symmetric)
         grads = []
         for e, x in enumerate(students):
-            v = sv["v_all"][e]
-            y = ops.gemm_tn(k2[e], v)                                                   # K2 V^T-rows
-            q = ops.gemm_tn(v, y)                                                       # Q = V K2 V^T (symmetric)
+            q = qs[e]
             mu = sv["means"][e].view(1, d_s)
             bias = ops.gemm_nt(mu, q).view(d_s)                                         # mu Q
             x = ops.as_supported(x)
             dx = ops.gemm_nt(x, q, bias=bias)                                           # (X - 1 mu^T) Q
             grads.append(dx.view(x.shape[0], x.shape[1], d_s))
         return grads
+
+    def _eigvec_adjoint_leading(self, sv: dict, gvt: torch.Tensor) -> list[torch.Tensor]:
+        """Q = V K2 V^T (the adjoint of `leading k eigenvectors of G`, see ``eigvec_k2``) WITHOUT the trailing
+        eigenvectors.  K2 couples a leading vector j with (a) the other leading vectors -- a k x k block from V_k
+        alone -- and (b) every trailing vector i through v_i v_i^T g_j / (lam_j - lam_i), which summed over i is
+        (lam_j I - G)^{-1} applied to the part of g_j orthogonal to the leading space: k shifted solves with the
+        tridiagonal form G = Q_H T Q_H^T that the forward already has.
+            Q = V_k^T (K2_kk V_k + Y) + Y^T V_k,    rows of Y:  y_j = P_perp (lam_j I - G)^{-1} P_perp g_j."""
+        ts, E, kmax = sv["s_ts"], sv["E"], sv["kmax"]
+        v_k = sv["v_all"][:, :kmax].contiguous()                                        # (E, kmax, d_s) rows v_j
+        lam_k = sv["lam"][:, :kmax].contiguous()
+        qs = []
+        m_kk = torch.stack([ops.gemm_nt(v_k[e], gvt[e]) for e in range(E)])            # M_kk[i][j] = v_i . g_j
+        k2 = ops.eigvec_k2(m_kk, lam_k)                                                 # (E, kmax, kmax), symmetric
+        # R^T rows r_j = g_j - sum_i M_kk[i][j] v_i     (P_perp g_j)
+        r = torch.stack([gvt[e] - ops.gemm_tn(m_kk[e], v_k[e]) for e in range(E)])
+        z = ops.tridiag_shifted_solve(ts, lam_k, ops.tridiag_apply_q(ts, r.contiguous(), transpose=True))
+        y = -ops.tridiag_apply_q(ts, z, transpose=False)                                # (lam_j I - G)^{-1} r_j
+        for e in range(E):
+            ye = y[e] - ops.gemm_tn(ops.gemm_nt(v_k[e], y[e]), v_k[e])                  # P_perp again: y - (y V_k^T) V_k
+            w_e = ops.gemm_tn(k2[e], v_k[e]) + ye                                       # K2_kk V_k + Y   (kmax x d_s)
+            qs.append(ops.gemm_tn(v_k[e], w_e) + ops.gemm_tn(ye, v_k[e]))               # V_k^T W + Y^T V_k
+        return qs
 
     def _distances(self, students: list[torch.Tensor], keys: list[int], teachers: list[torch.Tensor]) -> torch.Tensor:
         """d_grass_sq (E, L) (layer_selector.py:86-105), differentiable w.r.t. the student tokens."""

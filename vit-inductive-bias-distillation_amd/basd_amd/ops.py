@@ -291,6 +291,28 @@ def tridiag_eigenvectors(ts: TridiagState, k: int, first: int = 0, count: int | 
     return vecs
 
 
+def tridiag_apply_q(ts: TridiagState, x: torch.Tensor, transpose: bool) -> torch.Tensor:
+    """Rows of x (batch, k, n) times the reflector product of the factorisation: Q x (back to the original basis) or
+    Q^T x (``transpose``: into the tridiagonal's basis)."""
+    batch, k, n = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32 and batch == ts.d.shape[0] and n == ts.d.shape[1]
+    out = torch.empty_like(x)
+    _lib.call("basd_tridiag_apply_q", ts.tau.data_ptr(), ts.vh.data_ptr(), n, k, batch, x.data_ptr(), out.data_ptr(), k,
+              int(bool(transpose)), _stream())
+    return out
+
+
+def tridiag_shifted_solve(ts: TridiagState, shifts: torch.Tensor, rhs: torch.Tensor) -> torch.Tensor:
+    """x[z][t] = (T_z - shifts[z][t] I)^{-1} rhs[z][t]  (rhs (batch, k, n) in the tridiagonal's basis; the shifts are
+    eigenvalues: LU with partial pivoting, tiny pivots perturbed -- project the singular direction out afterwards)."""
+    batch, k, n = rhs.shape
+    assert rhs.is_contiguous() and shifts.dtype == torch.float32 and shifts.shape[0] == batch and shifts.stride(1) == 1
+    out = torch.empty_like(rhs)
+    _lib.call("basd_tridiag_shifted_solve", ts.d.data_ptr(), ts.e.data_ptr(), shifts.data_ptr(), shifts.stride(0), n, k,
+              batch, rhs.data_ptr(), out.data_ptr(), _stream())
+    return out
+
+
 def sort_extract(W: torch.Tensor, colnorm: torch.Tensor, kmax: int, rows: int | None = None):
     batch, n, rows_tot = W.shape
     rows = rows_tot if rows is None else rows

@@ -614,7 +614,9 @@ __global__ void __launch_bounds__(256) cluster_orth_kernel(const float* __restri
 // Eigenvectors of A from those of T:  x = H_0 H_1 ... H_{n-2} z.   One wave per vector, the vector in
 // registers (n <= 64 * EPL).  grid = (ceil(k/4), batch), block = 256.  out: (k x n) rows.
 // ---------------------------------------------------------------------------
-template <int EPL>
+// FWD = false: out = Q z = H_0 H_1 ... H_{n-2} z (eigenvectors of T -> eigenvectors of A);
+// FWD = true : out = Q^T z = H_{n-2} ... H_0 z (a vector of the original space -> the tridiagonal's basis).
+template <int EPL, bool FWD = false>
 __global__ void __launch_bounds__(256) backtransform_kernel(const float* __restrict__ Vh,
                                                             const float* __restrict__ tau, int n, int k,
                                                             const float* __restrict__ Z, float* __restrict__ out,
@@ -630,7 +632,8 @@ __global__ void __launch_bounds__(256) backtransform_kernel(const float* __restr
         const int r = lane + 64 * i;
         x[i] = r < n ? zz[r] : 0.f;
     }
-    for (int j = n - 2; j >= 0; --j) {
+    for (int jj = 0; jj <= n - 2; ++jj) {
+        const int j = FWD ? jj : n - 2 - jj;
         const float tj = tz[j];
         if (tj == 0.f) continue;
         const float* vj = Vz + (long)j * n;
@@ -733,6 +736,105 @@ __global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __re
     if (host_mirror && status && z == 0 && tid < 8) host_mirror[gridDim.x + tid] = status[tid];
 }
 
+
+// ---------------------------------------------------------------------------
+// x = (T - shift I)^{-1} rhs for k right-hand sides per tridiagonal, each with its own shift that IS (to round-off)
+// an eigenvalue of T: slagtf LU with partial pivoting + ONE slagts-style solve with the pivot perturbation that
+// inverse iteration uses, so the answer is finite: rhs's component along the shift's own eigenvector is amplified
+// by at most 1 / (eps ||T||) -- the caller projects that direction out (it asks for the solve on the orthogonal
+// complement).  Same thread-per-vector LDS layout as tridiag_invit_kernel.  grid = (ceil(k/vpw), batch), block 64.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) tridiag_shifted_solve_kernel(const float* __restrict__ d,
+                                                                   const float* __restrict__ e,
+                                                                   const float* __restrict__ shifts, int shift_stride,
+                                                                   int n, int k, int vpw,
+                                                                   const float* __restrict__ rhs, float* __restrict__ X) {
+    extern __shared__ float sm[];
+    __shared__ float red[32];
+    const int z = blockIdx.y, tid = threadIdx.x;
+    const float* dz = d + (long)z * n;
+    const float* ez = e + (long)z * n;
+    const float tnorm = tridiag_norm(dz, ez, n, tid, 64, red);
+    const int t = blockIdx.x * vpw + tid;
+    if (tid >= vpw || t >= k) return;
+    const float eps = 1.1920929e-7f;
+    const float tol = eps * tnorm + 1e-37f;
+    const long S = (long)n * vpw;
+    float* a = sm + 0 * S + tid;                   // element i at a[i * vpw]
+    float* b = sm + 1 * S + tid;
+    float* c = sm + 2 * S + tid;
+    float* d2 = sm + 3 * S + tid;
+    float* in = sm + 4 * S + tid;
+    float* x = sm + 5 * S + tid;
+    const float l = shifts[(long)z * shift_stride + t];
+    const float* r = rhs + ((long)z * k + t) * n;
+    for (int i = 0; i < n; ++i) {
+        a[i * vpw] = dz[i] - l;
+        const float ei = i < n - 1 ? ez[i] : 0.f;
+        b[i * vpw] = ei;
+        c[i * vpw] = ei;
+        d2[i * vpw] = 0.f;
+        in[i * vpw] = 0.f;
+        x[i * vpw] = r[i];
+    }
+    {   // slagtf
+        float ai = a[0];
+        float scale1 = fabsf(ai) + (n > 1 ? fabsf(b[0]) : 0.f);
+        for (int i = 0; i < n - 1; ++i) {
+            const float ci = c[i * vpw], bi = b[i * vpw];
+            const float a1 = a[(i + 1) * vpw];
+            const float b1 = i < n - 2 ? b[(i + 1) * vpw] : 0.f;
+            const float scale2 = fabsf(ci) + fabsf(a1) + fabsf(b1);
+            const float piv1 = ai == 0.f ? 0.f : fabsf(ai) / scale1;
+            const float piv2 = ci == 0.f ? 0.f : fabsf(ci) / scale2;
+            float a_next;
+            if (ci == 0.f || piv2 <= piv1) {
+                const float mult = ci == 0.f ? 0.f : ci / ai;
+                c[i * vpw] = mult;
+                a_next = a1 - mult * bi;
+            } else {
+                in[i * vpw] = 1.f;
+                const float mult = ai / ci;
+                a[i * vpw] = ci;
+                a_next = bi - mult * a1;
+                if (i < n - 2) {
+                    d2[i * vpw] = b1;
+                    b[(i + 1) * vpw] = -mult * b1;
+                }
+                b[i * vpw] = a1;
+                c[i * vpw] = mult;
+            }
+            a[(i + 1) * vpw] = a_next;
+            ai = a_next;
+            scale1 = scale2;
+        }
+    }
+    // forward substitution (P L)
+    float prev = x[0];
+    for (int i = 1; i < n; ++i) {
+        const float ci = c[(i - 1) * vpw], flag = in[(i - 1) * vpw];
+        const float xi = x[i * vpw];
+        float keep, next;
+        if (flag == 0.f) { keep = prev; next = xi - ci * prev; }
+        else { keep = xi; next = prev - ci * xi; }
+        x[(i - 1) * vpw] = keep;
+        prev = next;
+    }
+    x[(n - 1) * vpw] = prev;
+    // back substitution (U) with perturbed tiny pivots
+    float x1 = 0.f, x2 = 0.f;
+    float* out = X + ((long)z * k + t) * n;
+    for (int i = n - 1; i >= 0; --i) {
+        float tmp = x[i * vpw] - b[i * vpw] * x1 - d2[i * vpw] * x2;
+        float ak = a[i * vpw];
+        if (fabsf(ak) < tol) ak = copysignf(tol, ak == 0.f ? 1.f : ak);
+        tmp /= ak;
+        out[i] = tmp;
+        x2 = x1;
+        x1 = tmp;
+    }
+}
+
 }  // namespace basd
 
 using namespace basd;
@@ -794,6 +896,39 @@ int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, f
     BASD_CHECK_ARG(d && e && vals_desc && n > 0 && batch > 0);
     if (n > 8192) return BASD_EUNSUPPORTED;
     sturm_bisect_kernel<<<dim3((n + 63) / 64, batch), 1024, 0, stream>>>(d, e, n, vals_desc);
+    BASD_RETURN_LAST();
+}
+
+// out (batch, k_stride, n) rows = Q x or Q^T x for the rows of x (batch, k, n); Q = H_0 ... H_{n-2} of basd_tridiag.
+int basd_tridiag_apply_q(const float* tau, const float* vh, int n, int k, int batch, const float* x, float* out,
+                         int k_stride, int transpose, hipStream_t stream) {
+    BASD_CHECK_ARG(tau && vh && x && out && n > 1 && k > 0 && batch > 0 && k_stride >= k);
+    const dim3 grid((k + 3) / 4, batch);
+#define BASD_APPLY_Q(E)                                                                                          \
+    do {                                                                                                          \
+        if (transpose) backtransform_kernel<E, true><<<grid, 256, 0, stream>>>(vh, tau, n, k, x, out, k_stride);  \
+        else backtransform_kernel<E, false><<<grid, 256, 0, stream>>>(vh, tau, n, k, x, out, k_stride);           \
+    } while (0)
+    if (n <= 192) BASD_APPLY_Q(3);
+    else if (n <= 384) BASD_APPLY_Q(6);
+    else if (n <= 768) BASD_APPLY_Q(12);
+    else if (n <= 1024) BASD_APPLY_Q(16);
+    else return BASD_EUNSUPPORTED;
+#undef BASD_APPLY_Q
+    BASD_RETURN_LAST();
+}
+
+// x[z][t] = (T_z - shifts[z][t] I)^{-1} rhs[z][t] for t < k (see tridiag_shifted_solve_kernel); rhs, x: (batch, k, n).
+int basd_tridiag_shifted_solve(const float* d, const float* e, const float* shifts, int shift_stride, int n, int k,
+                               int batch, const float* rhs, float* x, hipStream_t stream) {
+    BASD_CHECK_ARG(d && e && shifts && rhs && x && n > 1 && k > 0 && batch > 0 && shift_stride >= k);
+    int vpw = (int)((144 * 1024) / (6 * sizeof(float) * (size_t)n));
+    if (vpw > 64) vpw = 64;
+    if (vpw < 1) return BASD_EUNSUPPORTED;
+    const size_t lds_a = sizeof(float) * 6 * (size_t)n * vpw;
+    if (lds_a > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)tridiag_shifted_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+    tridiag_shifted_solve_kernel<<<dim3((k + vpw - 1) / vpw, batch), 64, lds_a, stream>>>(d, e, shifts, shift_stride, n, k, vpw, rhs, x);
     BASD_RETURN_LAST();
 }
 
