@@ -316,3 +316,46 @@ def test_tridiag_mp_rank_matches_full_spectrum(dev, n, M):
     ref = (ev > lam.unsqueeze(1)).sum(1).clamp(max=n - 1).to(torch.int32)
     assert torch.equal(fast, ref), (fast, ref)
     assert int(fast.min()) >= 1
+
+
+@pytest.mark.parametrize("n", [384, 100, 45])
+def test_tridiag_apply_q_and_shifted_solve(dev, n):
+    """The reflector product in both directions and the shifted tridiagonal solve behind the multi-layer backward."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(3 * n)
+    x = torch.randn(2, 4 * n, n, generator=g)
+    x[:, :, :8] *= torch.linspace(6.0, 2.0, 8)
+    G0 = (x.transpose(1, 2) @ x).to(dev)
+    ts = ops.tridiag_eigenvalues(G0.clone())
+    eye = torch.eye(n, device=dev).repeat(2, 1, 1).contiguous()
+    q_rows = ops.tridiag_apply_q(ts, eye, transpose=False)          # row i = Q e_i  ->  q_rows = Q^T
+    Q = q_rows.transpose(1, 2).double()
+    assert (Q.transpose(1, 2) @ Q - torch.eye(n, device=dev, dtype=torch.float64)).abs().max() < 5e-5
+    T = torch.diag_embed(ts.d.double()) + torch.diag_embed(ts.e.double()[:, :n - 1], 1) + torch.diag_embed(ts.e.double()[:, :n - 1], -1)
+    assert ((Q @ T @ Q.transpose(1, 2) - G0.double()).abs().max() / G0.abs().max()) < 5e-6
+    v = torch.randn(2, 5, n, generator=g).to(dev)
+    back = ops.tridiag_apply_q(ts, ops.tridiag_apply_q(ts, v, transpose=True), transpose=False)
+    assert _rel(back, v.double()) < 5e-6
+    assert _rel(ops.tridiag_apply_q(ts, v, transpose=True), v.double() @ Q) < 5e-6      # rows: (Q^T v)^T = v^T Q
+    # a regular shift (between two eigenvalues): plain solve
+    vals = ts.vals.double()
+    shifts = (0.5 * (vals[:, 2:7] + vals[:, 3:8])).float().contiguous()                  # (2, 5)
+    sol = ops.tridiag_shifted_solve(ts, shifts, v)
+    for z in range(2):
+        for t in range(5):
+            ref = torch.linalg.solve(T[z] - shifts[z, t].double() * torch.eye(n, device=dev, dtype=torch.float64), v[z, t].double())
+            assert _rel(sol[z, t], ref) < 2e-3, (z, t, float(_rel(sol[z, t], ref)))
+    # an eigenvalue as the shift: finite, and exact on the orthogonal complement of its eigenvector
+    lam = ts.vals[:, :5].contiguous()
+    w_t = torch.linalg.eigh(T)[1].flip(2)[:, :, :5]                                       # eigenvectors of T (fp64)
+    rhs = v.double() - (v.double() @ w_t) @ w_t.transpose(1, 2)                            # rhs orthogonal to the leading 5
+    sol = ops.tridiag_shifted_solve(ts, lam, rhs.float().contiguous()).double()
+    assert torch.isfinite(sol).all()
+    sol = sol - (sol @ w_t) @ w_t.transpose(1, 2)
+    ev = torch.linalg.eigvalsh(T).flip(1)
+    for z in range(2):
+        for t in range(5):
+            pinv = torch.linalg.pinv(T[z] - ev[z, t] * torch.eye(n, device=dev, dtype=torch.float64), rtol=1e-9)
+            ref = pinv @ rhs[z, t]
+            ref = ref - w_t[z] @ (w_t[z].T @ ref)
+            assert _rel(sol[z, t], ref) < 5e-3, (z, t, float(_rel(sol[z, t], ref)))
