@@ -173,6 +173,80 @@ __global__ void __launch_bounds__(256) student_project_kernel(const T* __restric
     }
 }
 
+// Same, with the workgroup's (n_s x 64) slab of X staged in LDS by one coalesced pass (16-byte loads): the three
+// sweeps (weighted mean, trace, projection) then read LDS instead of pulling 256-byte row segments through L2
+// four or five times.  Needs 16-byte aligned rows and (n_s * 65) floats of LDS (n_s <= ~600).
+__device__ __forceinline__ float4 ld4f(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float4 ld4f(const __hip_bfloat16* p) {
+    const uint2 v = *(const uint2*)p;
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) student_project_lds_kernel(const T* __restrict__ X, long sb, long sn, int n_s,
+                                                                  int n_t, int D, const float* __restrict__ omega,
+                                                                  const int* __restrict__ tap0,
+                                                                  const int* __restrict__ tap1,
+                                                                  const float* __restrict__ lam,
+                                                                  const int* __restrict__ range0,
+                                                                  const int* __restrict__ range1,
+                                                                  float* __restrict__ mu_out,
+                                                                  float* __restrict__ tr_part, float* __restrict__ Ap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;                      // n_s x 64 slab, row-major
+    float* w = sm + (long)n_s * 64;      // n_s
+    __shared__ float red[4][64];
+    __shared__ float mu[64];
+    __shared__ float scratch[32];
+    const int b = blockIdx.y, d0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int cl = tid & 63, rg = tid >> 6, d = d0 + cl;
+    const bool live = d < D;
+    const T* Xb = X + (long)b * sb + d0;
+    for (int n = tid; n < n_s; n += 256) w[n] = omega[(long)b * n_s + n];
+    for (int idx = tid; idx < n_s * 16; idx += 256) {
+        const int row = idx >> 4, c4 = (idx & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d0 + c4 < D) v = ld4f(Xb + (long)row * sn + c4);        // D % 4 == 0: the quad is inside or outside
+        *(float4*)(xs + row * 64 + c4) = v;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int n = rg; n < n_s; n += 4) acc = fmaf(w[n], xs[n * 64 + cl], acc);
+    red[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        const float m = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        mu[cl] = m;
+        if (live) mu_out[(long)b * D + d] = m;
+    }
+    __syncthreads();
+    const float m = mu[cl];
+    float part = 0.f;
+    if (live)
+        for (int n = rg; n < n_s; n += 4) {
+            const float c = xs[n * 64 + cl] - m;
+            part = fmaf(w[n] * c, c, part);
+        }
+    const float tr = block_sum(part, scratch);
+    if (tid == 0) tr_part[(long)b * gridDim.x + blockIdx.x] = tr;
+    if (!live) return;
+    float* Ab = Ap + (long)b * n_t * D + d;
+    for (int j = rg; j < n_t; j += 4) {
+        const int n0 = range0 ? range0[j] : j, n1 = range1 ? range1[j] : j + 1;
+        float a = 0.f;
+        for (int n = n0; n < n1; ++n) {
+            float coef = 1.f;
+            if (tap0) {
+                const float l1 = lam[n];
+                coef = (tap0[n] == j ? 1.f - l1 : 0.f) + (tap1[n] == j ? l1 : 0.f);
+            }
+            a = fmaf(coef * w[n], xs[n * 64 + cl] - m, a);
+        }
+        Ab[(long)j * D] = a;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Teacher side: mix the L layers, (optionally) resample to the core grid, weighted-centre.
 //   Tbar[b, r, :] = sum_l mix_l T_l[b, r, :]                               (layer_selector.py:110-111)
@@ -593,12 +667,28 @@ int basd_student_project(const void* x, int dtype, long sb, long sn, int B, int 
     BASD_CHECK_ARG((n_t == n_s) == (tap0 == nullptr));
     const size_t lds = sizeof(float) * (size_t)n_s;
     const dim3 grid((D + 63) / 64, B);
-    if (dtype == BASD_DTYPE_F32)
-        student_project_kernel<float><<<grid, 256, lds, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
-    else if (dtype == BASD_DTYPE_BF16)
-        student_project_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
-    else
+    // LDS-staged variant: 16-byte aligned row quads and a slab that fits
+    const int esz = dtype == BASD_DTYPE_F32 ? 4 : 2;
+    const size_t lds_slab = sizeof(float) * (size_t)n_s * 65;
+    const bool staged = D % 4 == 0 && ((uintptr_t)x * 1) % 16 == 0 && (sb * esz) % 16 == 0 && (sn * esz) % 16 == 0 &&
+                        (esz == 4 || D % 8 == 0) && lds_slab <= 64 * 1024;      // >= 2 workgroups per CU
+    if (dtype == BASD_DTYPE_F32) {
+        if (staged) {
+            (void)hipFuncSetAttribute((const void*)student_project_lds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_slab);
+            student_project_lds_kernel<float><<<grid, 256, lds_slab, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+        } else {
+            student_project_kernel<float><<<grid, 256, lds, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+        }
+    } else if (dtype == BASD_DTYPE_BF16) {
+        if (staged) {
+            (void)hipFuncSetAttribute((const void*)student_project_lds_kernel<__hip_bfloat16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_slab);
+            student_project_lds_kernel<__hip_bfloat16><<<grid, 256, lds_slab, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+        } else {
+            student_project_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+        }
+    } else {
         return BASD_EINVAL;
+    }
     BASD_RETURN_LAST();
 }
 
