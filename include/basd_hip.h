@@ -84,10 +84,13 @@ int basd_syrk_splits(int krows, int cols, int n_mats);
  * x_ptrs: DEVICE array of base pointers; element (k, c) of X_z at x_ptrs[z] + (k / rows_per_batch)*sb +
  * (k % rows_per_batch)*sn + c*sd.  means / scales (nullable): n_mats*cols / n_mats floats on the device.
  * slabs: n_mats*splits*cols*cols floats of scratch (splits from basd_syrk_splits).  vec_ok: caller asserts
- * every base pointer is 16-byte aligned. */
+ * every base pointer is 16-byte aligned.  fold (nullable): (n_mats - fold_from) x fold_parts x cols row-tile column
+ * sums as left by basd_gemm_nt's epilogue; matrices z >= fold_from take their means from it (sum / krows) instead
+ * of `means`, folded inside the kernel. */
 int basd_syrk_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long sd, int rows_per_batch, int krows,
                     int cols, int n_mats, const float* means, const float* scales, int splits, float* slabs,
-                    float* out, long out_stride, int vec_ok, hipStream_t stream);
+                    float* out, long out_stride, int vec_ok, const float* fold, int fold_parts, int fold_from,
+                    hipStream_t stream);
 
 /* ---- one-sided Jacobi SVD / symmetric eigensolver ------------------------------------------ */
 

@@ -359,3 +359,23 @@ def test_tridiag_apply_q_and_shifted_solve(dev, n):
             ref = pinv @ rhs[z, t]
             ref = ref - w_t[z] @ (w_t[z].T @ ref)
             assert _rel(sol[z, t], ref) < 5e-3, (z, t, float(_rel(sol[z, t], ref)))
+
+
+def test_centered_grams_fold_means_from_projection_epilogue(dev):
+    """Teacher chain as the selector runs it: projection with row-tile column sums, then [uncentred / M, centred]
+    Grams whose means are folded inside the Gram kernel."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(17)
+    B, n_t, K, N = 37, 49, 256, 384
+    t = (torch.randn(B, K, n_t, generator=g) + 0.4).to(dev).transpose(1, 2)       # channel-major teacher
+    p = torch.randn(N, K, generator=g).to(dev) / 16
+    M = B * n_t
+    sums = torch.empty((1, (M + 127) // 128, N), device=dev)
+    z = ops.gemm_nt(t, p, col_sums=sums[0])
+    zd = t.double().reshape(-1, K) @ p.double().T
+    assert _rel(z, zd) < 2e-6
+    assert _rel(sums.sum(dim=(0, 1)), zd.sum(0)) < 2e-6
+    out, _ = ops.centered_grams([z, z], scales=[1.0 / M, 1.0], fold=(sums, 1))
+    c = zd - zd.mean(0)
+    assert _rel(out[0], zd.T @ zd / M) < 5e-6
+    assert _rel(out[1], c.T @ c) < 5e-6

@@ -25,7 +25,7 @@ SIGNATURES = {
     "basd_colmean": [vp, i32, i64, i64, i64, i32, i64, i32, i32, i32, i32, vp, vp, vp],
     "basd_colmean_multi": [vp, i32, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp],
     "basd_syrk_splits": [i32, i32, i32],
-    "basd_syrk_multi": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, i32, vp, vp, i64, i32, vp],
+    "basd_syrk_multi": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, i32, vp, vp, i64, i32, vp, i32, i32, vp],
     "basd_jacobi_workspace_ints": [i32, i32],
     "basd_jacobi_onesided": [vp, i64, i32, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp],
     "basd_sort_extract": [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],

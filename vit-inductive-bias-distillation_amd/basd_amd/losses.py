@@ -270,17 +270,15 @@ class GrassmannianLayerSelector(nn.Module):
     # ---- teacher side: ranks + subspaces -------------------------------------------------
     @torch.no_grad()
     def _teacher_projections(self, teachers: list[torch.Tensor]) -> tuple[list[torch.Tensor], torch.Tensor]:
-        """Per teacher layer z = tokens @ proj_t^T (M, d_s)   (layer_selector.py:72 / :135), plus the mean rows the
-        Gram launch wants: [0 (uncentred Gram) x L, column means of z (:35) x L] when M >= d_s, else the means
-        alone.  The means come out of the projection kernel's epilogue."""
+        """Per teacher layer z = tokens @ proj_t^T (M, d_s)   (layer_selector.py:72 / :135), plus the column sums of
+        every 128-row tile of z from the projection kernel's epilogue (L, tiles, d_s): the Gram launch folds the
+        column means of z (:35) from them, so no separate reduction sits on the teacher chain."""
         d_s, L = self.student_dim, len(teachers)
         M = teachers[0].shape[0] * teachers[0].shape[1]
-        off = L if M >= d_s else 0
-        means = torch.zeros((off + L, d_s), device=teachers[0].device, dtype=torch.float32)
+        sums = torch.empty((L, (M + 127) // 128, d_s), device=teachers[0].device, dtype=torch.float32)
         proj_t = self.proj_t.float().contiguous()
-        zs = [ops.gemm_nt(ops.as_supported(t), proj_t, col_mean=True, mean_out=means[off + l])[0]
-              for l, t in enumerate(teachers)]
-        return zs, means
+        zs = [ops.gemm_nt(ops.as_supported(t), proj_t, col_sums=sums[l]) for l, t in enumerate(teachers)]
+        return zs, sums
 
     def _teacher_grams(self, teachers: list[torch.Tensor], projected: list[torch.Tensor] | None = None):
         """Per teacher layer: projected tokens -> uncentred Gram / M (for the MP rank, layer_selector.py:12-15)
@@ -291,16 +289,16 @@ class GrassmannianLayerSelector(nn.Module):
         M = B * n_t
         proj_t = self.proj_t.float().contiguous()
         n_u = d_s if M >= d_s else M
-        zs, means = projected if projected is not None else self._teacher_projections(teachers)
+        zs, sums = projected if projected is not None else self._teacher_projections(teachers)
         if n_u == d_s:
             # uncentred / M and centred Grams of every layer's projected tokens: one symmetric launch,
             # laid out [uncentred 0..L-1, centred 0..L-1]
-            stack, _ = ops.centered_grams(zs + zs, scales=[1.0 / M] * L + [1.0] * L, means=means)
+            stack, _ = ops.centered_grams(zs + zs, scales=[1.0 / M] * L + [1.0] * L, fold=(sums, L))
             return stack[:L], stack[L:], M, stack
         g_u = torch.empty((L, n_u, n_u), device=proj_t.device, dtype=torch.float32)
         for l, z in enumerate(zs):
             g_u[l] = _uncentred_gram(z)
-        g_c, _ = ops.centered_grams(zs, means=means)
+        g_c, _ = ops.centered_grams(zs, fold=(sums, 0))
         return g_u, g_c, M, None
 
     @torch.no_grad()

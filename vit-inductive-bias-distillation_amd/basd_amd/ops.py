@@ -75,7 +75,7 @@ def _tok3(x: torch.Tensor) -> tuple[int, int, int, int, int, int]:
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, scale: float = 1.0, out: torch.Tensor | None = None,
             a_batch_stride: int = 0, b_batch_stride: int = 0, batch: int = 1, rows: int | None = None,
             n_cols: int | None = None, bias: torch.Tensor | None = None, beta: float = 0.0,
-            col_mean: bool = False, mean_out: torch.Tensor | None = None):
+            col_mean: bool = False, mean_out: torch.Tensor | None = None, col_sums: torch.Tensor | None = None):
     """C = beta * C + scale * A @ B.T - bias.  A: (B,N,K) or (M,K) view in fp32/bf16; B: (N,K) fp32 row-major.
     With batch > 1, element z uses a/b advanced by the given batch strides.  ``col_mean``: also return the column
     means of C (from the kernel's epilogue; no second pass over C) -> (C, means (batch?, N))."""
@@ -89,6 +89,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, scale: float = 1.0, out: torch.
     if out is None:
         out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=a.device, dtype=torch.float32)
     part = mean = None
+    if col_sums is not None:            # row-tile column sums only (folded later, e.g. inside centered_grams)
+        assert col_sums.is_contiguous() and col_sums.numel() == batch * ((M + 127) // 128) * N
+        part = col_sums
     if col_mean:
         part = torch.empty((batch, (M + 127) // 128, N), device=a.device, dtype=torch.float32)
         mean = mean_out if mean_out is not None else \
@@ -158,8 +161,8 @@ def column_means(xs: list[torch.Tensor]) -> torch.Tensor:
 
 def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None,
                    scales: list[float] | None = None, out: torch.Tensor | None = None,
-                   splits: int | None = None, means: torch.Tensor | None = None
-                   ) -> tuple[torch.Tensor, torch.Tensor]:
+                   splits: int | None = None, means: torch.Tensor | None = None,
+                   fold: tuple[torch.Tensor, int] | None = None) -> tuple[torch.Tensor, torch.Tensor]:
     """Gram matrices of same-layout (B,N,D) / (M,D) views in two launches (+ reductions):
     out[z] = scales[z] * (X_z - 1 mu_z^T)^T (X_z - 1 mu_z^T), mu_z the column means (0 where not centred).
     ``means``: column means already queued by ``column_means`` (lets the caller put other work between the two
@@ -167,9 +170,16 @@ def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None
     (dt, sb, sn, sd, rpb), rows, cols, vec_ok = _gram_layout(xs)
     n, dev = len(xs), xs[0].device
     table = _ptr_table(xs)
-    if means is None:
+    if fold is not None:
+        part, fold_from = fold
+        assert part.is_contiguous() and part.dtype == torch.float32 and part.shape[0] == n - fold_from
+        means_used = None
+        centered = None
+    elif means is None:
         means = column_means(xs)
-    if centered is not None and not all(centered):
+    if fold is not None:
+        pass
+    elif centered is not None and not all(centered):
         keep = _device_consts(tuple(1.0 if c else 0.0 for c in centered), torch.float32, dev)
         means_used = means * keep.unsqueeze(1)
     else:
@@ -183,8 +193,10 @@ def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None
     if out is None:
         out = torch.empty((n, cols, cols), device=dev, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.shape == (n, cols, cols) and out[0].is_contiguous()
-    _lib.call("basd_syrk_multi", table.data_ptr(), dt, sb, sn, sd, rpb, rows, cols, n, means_used.data_ptr(),
-              _ptr(sc), splits, slabs.data_ptr(), out.data_ptr(), out.stride(0), vec_ok, _stream())
+    _lib.call("basd_syrk_multi", table.data_ptr(), dt, sb, sn, sd, rpb, rows, cols, n, _ptr(means_used),
+              _ptr(sc), splits, slabs.data_ptr(), out.data_ptr(), out.stride(0), vec_ok,
+              _ptr(fold[0]) if fold is not None else None, fold[0].shape[1] if fold is not None else 0,
+              fold[1] if fold is not None else 0, _stream())
     return out, means
 
 

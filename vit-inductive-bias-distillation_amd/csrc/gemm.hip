@@ -426,7 +426,8 @@ __device__ __forceinline__ void tri_tile(int p, int& mi, int& ni) {
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) syrk_tn_kernel(const void* const* __restrict__ ptrs, GemmOperand X, int cols,
                                                       int Krows, int splits, int n_mats, int pairs,
-                                                      const float* __restrict__ means, float* __restrict__ slabs) {
+                                                      const float* __restrict__ means, float* __restrict__ slabs,
+                                                      const float* __restrict__ fold, int fold_parts, int fold_from) {
     __shared__ __attribute__((aligned(16))) float lds[2 * TN_BK * 128];
     // XCD-aware decode of the 1-D grid: workgroup ids that agree mod 8 run on one XCD (one L2).  The tile
     // pairs of one (matrix, split) unit read the same rows, so they are given ids of one residue class and
@@ -477,7 +478,22 @@ __global__ void __launch_bounds__(256) syrk_tn_kernel(const void* const* __restr
     float reg[2][4][4], m4[4];
     TnCursor cu;
     tn_cursor_init(cu, X, k_begin, t);
-    tn_mean4(mean, cols, col0, t, m4);
+    if (fold && z >= fold_from) {
+        // column means folded here from the row-tile sums that the producing GEMM's epilogue left behind
+        // (fixed order: deterministic) -- one small kernel less on the teacher chain, which is the step's
+        // critical path and gets its small launches starved by the student chain's long Gram launch
+        const float* fp = fold + (long)(z - fold_from) * fold_parts * cols;
+        const int c = col0 + (t & 31) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = 0.f;
+            if (c + e < cols)
+                for (int p = 0; p < fold_parts; ++p) s += fp[(long)p * cols + c + e];
+            m4[e] = s * (1.f / Krows);
+        }
+    } else {
+        tn_mean4(mean, cols, col0, t, m4);
+    }
     if (loader && k_begin < k_end) tn_load<T, VEC>(X, cu, k_end, cols, k_begin, col0, t, m4, reg);
     const int i = lane & 31, h = lane >> 5;
     for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
@@ -791,19 +807,21 @@ int basd_syrk_splits(int krows, int cols, int n_mats) {
 //   slabs: n_mats*splits*cols*cols floats of scratch, splits from basd_syrk_splits.
 int basd_syrk_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long sd, int rows_per_batch, int krows,
                     int cols, int n_mats, const float* means, const float* scales, int splits, float* slabs,
-                    float* out, long out_stride, int vec_ok, hipStream_t stream) {
+                    float* out, long out_stride, int vec_ok, const float* fold, int fold_parts, int fold_from,
+                    hipStream_t stream) {
     BASD_CHECK_ARG(x_ptrs && slabs && out && krows > 0 && cols > 0 && n_mats > 0 && splits >= 1 && rows_per_batch > 0);
     BASD_CHECK_ARG(out_stride >= (long)cols * cols);
+    BASD_CHECK_ARG(!fold || (fold_parts > 0 && fold_from >= 0 && fold_from <= n_mats));
     GemmOperand X{nullptr, sb, sn, sd, rows_per_batch, 0};
     const int tiles = (cols + BM - 1) / BM, pairs = tiles * (tiles + 1) / 2;
     const dim3 grid(pairs * splits * n_mats);
     if (dtype == BASD_DTYPE_F32) {
         const bool vec = vec_ok && sd == 1 && sb % 4 == 0 && sn % 4 == 0;
-        if (vec) syrk_tn_kernel<float, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs);
-        else syrk_tn_kernel<float, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs);
+        if (vec) syrk_tn_kernel<float, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);
+        else syrk_tn_kernel<float, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);
     } else if (dtype == BASD_DTYPE_BF16) {
-        if (sd == 1) syrk_tn_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs);
-        else syrk_tn_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs);
+        if (sd == 1) syrk_tn_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);
+        else syrk_tn_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);
     } else {
         return BASD_EINVAL;
     }
