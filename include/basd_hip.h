@@ -1,7 +1,7 @@
 /* C ABI of libbasd_hip.so -- the MI355X (gfx950) kernels behind the BASD loss path.
  *
  * The reference (indrajeetadityaroy9/vit-inductive-bias-distillation) is pure Python: its
- * "FFI" for this path is the set of torch operator call sites in src/losses/*.py.  Each entry
+ * "FFI" for this path is the set of torch operator call sites in src/losses/<module>.py.  Each entry
  * point below replaces one (or a fused group) of those call sites; the file:line it stands in
  * for is quoted on every declaration (paths relative to the reference root).
  *
@@ -170,6 +170,18 @@ int basd_grassmann_distance(const float* colnorm, int stride, const int* k_arr, 
                             const int* sw_index, int items, float* d_out, float* theta_out, hipStream_t stream);
 
 int basd_sqrt_clamp(const float* in, float* out, long count, hipStream_t stream);
+
+/* Everything of the selector that follows the rank read-back, queued by one call (layer_selector.py:36-37, :92,
+ * :95-105): leading kmax eigenvectors of the E student / L centred teacher Grams from their basd_tridiag
+ * factorisations (t_* / s_*: d, e, tau, vh, vals), S[:k], the teacher bases rotated by proj_s^T, the E x L cosine
+ * matrices, their singular values and d_grass_sq (E, L) -> d_out.  Scratch (floats unless noted): z_s, v_s
+ * (E kmax d_s), z_t, u_t, u_rot (L kmax d_s), sw (L kmax), cos (E L kmax^2), k_arr (E L ints), sigma (E L kmax),
+ * flags (basd_jacobi_workspace_ints(E L, 20) ints); sw_index: (E L) ints, item e*L+l -> l. */
+int basd_selector_tail(const float* t_d, const float* t_e, const float* t_tau, const float* t_vh, const float* t_vals,
+                       const float* s_d, const float* s_e, const float* s_tau, const float* s_vh, const float* s_vals,
+                       int d_s, int E, int L, int kmax, const int* ranks, const float* proj_s_t, float* z_s,
+                       float* v_s, float* z_t, float* u_t, float* u_rot, float* sw, float* cos, int* k_arr,
+                       const int* sw_index, float* sigma, int* flags, float* d_out, hipStream_t stream);
 
 /* ---- attention-weighted Procrustes loss ------------------------------------------------------ */
 

@@ -469,6 +469,10 @@ class GrassmannianLayerSelector(nn.Module):
         dev = ranks_dev.device
         ranks = ranks_host if ranks_host is not None else self._read_ranks(st, keys)
         kmax = max(ranks)
+        if (not want_grad and st["tri"] and not st["stud_jacobi"] and "t_ts" in st and "s_ts" in st
+                and st["student_stream"] is None):
+            # the common case: one library call queues the whole tail (host time is on the step's critical path)
+            return ops.selector_tail(st["t_ts"], o_c, L, st["s_ts"], kmax, ranks_dev, self._proj_s_transposed()), None
         n_stud = d_s if want_grad else kmax
         # student eigenvectors (on the student chain's stream when there is one)
         ss = st["student_stream"]

@@ -325,6 +325,30 @@ def tridiag_shifted_solve(ts: TridiagState, shifts: torch.Tensor, rhs: torch.Ten
     return out
 
 
+def selector_tail(t_ts: TridiagState, t_first: int, L: int, s_ts: TridiagState, kmax: int, ranks_dev: torch.Tensor,
+                  proj_s_t: torch.Tensor) -> torch.Tensor:
+    """d_grass_sq (E, L) from the two factorisations and the device-side ranks: everything behind the rank
+    read-back in ONE library call (see basd_selector_tail); scratch comes from two allocations."""
+    E, n = s_ts.vals.shape
+    dev = s_ts.vals.device
+    items = E * L
+    kn, kk = kmax * n, kmax * kmax
+    sizes = [E * kn, E * kn, L * kn, L * kn, L * kn, L * kmax, items * kk, items * kmax, items]
+    buf = torch.empty((sum(sizes),), device=dev, dtype=torch.float32)
+    z_s, v_s, z_t, u_t, u_rot, sw, cos, sigma, d_out = torch.split(buf, sizes)
+    ints = torch.empty((items + _lib.query("basd_jacobi_workspace_ints", items, MAX_SWEEPS),), device=dev,
+                       dtype=torch.int32)
+    sw_index = _device_consts(tuple(range(L)) * E, torch.int32, dev)
+    sl = slice(t_first, t_first + L)
+    _lib.call("basd_selector_tail", t_ts.d[sl].data_ptr(), t_ts.e[sl].data_ptr(), t_ts.tau[sl].data_ptr(),
+              t_ts.vh[sl].data_ptr(), t_ts.vals[sl].data_ptr(), s_ts.d.data_ptr(), s_ts.e.data_ptr(),
+              s_ts.tau.data_ptr(), s_ts.vh.data_ptr(), s_ts.vals.data_ptr(), n, E, L, kmax, ranks_dev.data_ptr(),
+              proj_s_t.data_ptr(), z_s.data_ptr(), v_s.data_ptr(), z_t.data_ptr(), u_t.data_ptr(), u_rot.data_ptr(),
+              sw.data_ptr(), cos.data_ptr(), ints.data_ptr(), sw_index.data_ptr(), sigma.data_ptr(),
+              ints[items:].data_ptr(), d_out.data_ptr(), _stream())
+    return d_out.view(E, L)
+
+
 def sort_extract(W: torch.Tensor, colnorm: torch.Tensor, kmax: int, rows: int | None = None):
     batch, n, rows_tot = W.shape
     rows = rows_tot if rows is None else rows

@@ -3,6 +3,7 @@
 //   grassmann_distance_kernel: sigma -> theta = acos(min(sigma, 1 - eps)) ->
 //                              d = sum(sw * theta^2) / sum(sw)                        (:99-105)
 #include "basd_common.h"
+#include "../../include/basd_hip.h"
 
 namespace basd {
 
@@ -98,6 +99,63 @@ int basd_sqrt_clamp(const float* in, float* out, long count, hipStream_t stream)
     BASD_CHECK_ARG(in && out && count > 0);
     sqrt_clamp_kernel<<<(unsigned)((count + 255) / 256), 256, 0, stream>>>(in, out, count);
     BASD_RETURN_LAST();
+}
+
+}  // extern "C"
+
+namespace basd {
+__global__ void repeat_ranks_kernel(const int* __restrict__ ranks, int L, int items, int* __restrict__ k_arr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < items) k_arr[i] = ranks[i % L];
+}
+}  // namespace basd
+
+extern "C" {
+
+// The part of the selector that follows the rank read-back (layer_selector.py:36-37, :92, :95-105), queued by ONE
+// call: leading kmax eigenvectors of the E student and L (centred) teacher Grams from their tridiagonal
+// factorisations, S[:k] of the teacher, rotation of the teacher bases by proj_s^T (proj_s folded, :88/:99), the
+// E x L cosine matrices Vt_s[:k] U_t, their singular values (one-sided Jacobi, orders ranks[l]) and
+// d_grass_sq (E, L).  Host time matters here: these ~14 launches sit between the read-back and the caller's
+// backward, and a dozen separate FFI calls cost several times the launches themselves.
+//   t_* / s_*: d, e, tau (x n), vh (x n x n), vals (x n) of the L teacher (centred) / E student matrices, n = d_s
+//   scratch: z_s, v_s (E kmax n), z_t, u_t, u_rot (L kmax n), sw (L kmax), cos (E L kmax kmax), k_arr (E L),
+//            sigma (E L kmax), flags (basd_jacobi_workspace_ints(E L, 20)); sw_index: (E L) = l of item e*L+l
+int basd_selector_tail(const float* t_d, const float* t_e, const float* t_tau, const float* t_vh, const float* t_vals,
+                       const float* s_d, const float* s_e, const float* s_tau, const float* s_vh, const float* s_vals,
+                       int d_s, int E, int L, int kmax, const int* ranks, const float* proj_s_t, float* z_s,
+                       float* v_s, float* z_t, float* u_t, float* u_rot, float* sw, float* cos, int* k_arr,
+                       const int* sw_index, float* sigma, int* flags, float* d_out, hipStream_t stream) {
+    BASD_CHECK_ARG(t_d && s_d && ranks && proj_s_t && z_s && v_s && z_t && u_t && u_rot && sw && cos && k_arr &&
+                   sw_index && sigma && flags && d_out && E > 0 && L > 0 && kmax > 0 && kmax <= d_s);
+    int st = basd_tridiag_eigenvectors(s_d, s_e, s_tau, s_vh, s_vals, d_s, kmax, E, z_s, v_s, kmax, stream);
+    if (st) return st;
+    st = basd_tridiag_eigenvectors(t_d, t_e, t_tau, t_vh, t_vals, d_s, kmax, L, z_t, u_t, kmax, stream);
+    if (st) return st;
+    for (int l = 0; l < L; ++l) {
+        st = basd_sqrt_clamp(t_vals + (long)l * d_s, sw + (long)l * kmax, kmax, stream);
+        if (st) return st;
+    }
+    const long kn = (long)kmax * d_s, kk = (long)kmax * kmax;
+    st = basd_gemm_nt(u_t, BASD_DTYPE_F32, 0, d_s, 1, 1 << 30, 0, proj_s_t, d_s, 0, L * kmax, d_s, d_s, 1, u_rot, d_s,
+                      (long)L * kn, 1.f, nullptr, 0.f, nullptr, nullptr, stream);
+    if (st) return st;
+    if (L == 1) {
+        st = basd_gemm_nt(v_s, BASD_DTYPE_F32, 0, d_s, 1, 1 << 30, kn, u_rot, d_s, 0, kmax, kmax, d_s, E, cos, kmax, kk,
+                          1.f, nullptr, 0.f, nullptr, nullptr, stream);
+        if (st) return st;
+    } else {
+        for (int e = 0; e < E; ++e) {
+            st = basd_gemm_nt(v_s + e * kn, BASD_DTYPE_F32, 0, d_s, 1, 1 << 30, 0, u_rot, d_s, kn, kmax, kmax, d_s, L,
+                              cos + (long)e * L * kk, kmax, kk, 1.f, nullptr, 0.f, nullptr, nullptr, stream);
+            if (st) return st;
+        }
+    }
+    const int items = E * L;
+    basd::repeat_ranks_kernel<<<(items + 255) / 256, 256, 0, stream>>>(ranks, L, items, k_arr);
+    st = basd_jacobi_onesided(cos, kk, kmax, kmax, kmax, items, k_arr, sigma, kmax, 20, 0.f, flags, nullptr, stream);
+    if (st) return st;
+    return basd_grassmann_distance(sigma, kmax, k_arr, sw, kmax, sw_index, items, d_out, nullptr, stream);
 }
 
 }  // extern "C"
