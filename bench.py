@@ -74,14 +74,14 @@ def one_step(mod, inp, leaves, logits, bucket):
     mod.layer_selector.log_temperatures.grad = None
     loss = mod(logits, inp.targets, leaves, inp.teacher, inp.attn)
     loss.backward()
-    # stand-in student head: per-feature bias gradients of every extraction layer fill the front of the
-    # student part of the bucket (the rest keeps its DeiT-S size so that the all-reduce volume is real)
-    off = 0
-    for l in mod.token_layers:
-        g = leaves[l].grad
-        d = g.shape[-1]
-        bucket.student_view[off:off + d] = g.sum(dim=(0, 1))
-        off += d
+    # stand-in student head: per-feature bias gradients (token sums) of every extraction layer fill the front of
+    # the student part of the bucket (the rest keeps its DeiT-S size so that the all-reduce volume is real);
+    # one batched column-sum launch of the library instead of a torch reduction per layer
+    grads = [leaves[l].grad for l in mod.token_layers]
+    rows = grads[0].shape[0] * grads[0].shape[1]
+    sums = ops.column_means(grads)                      # (E, D) means over the B * N token rows
+    bucket.student_view[: sums.numel()].copy_(sums.reshape(-1))
+    bucket.student_view[: sums.numel()].mul_(rows)
     bucket.pack_loss_grads()            # + the 4 selector temperatures the reference forgets to reduce
     bucket.all_reduce_mean()            # RCCL over xGMI; no-op at world size 1
     return loss

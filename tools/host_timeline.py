@@ -28,12 +28,11 @@ for _ in range(N):
     ops.trace("fwd_returned")
     loss.backward()
     ops.trace("bwd_queued")
-    off = 0
-    for l in mod.token_layers:
-        g = leaves[l].grad
-        d = g.shape[-1]
-        bucket.student_view[off:off + d] = g.sum(dim=(0, 1))
-        off += d
+    grads = [leaves[l].grad for l in mod.token_layers]
+    rows = grads[0].shape[0] * grads[0].shape[1]
+    sums = ops.column_means(grads)
+    bucket.student_view[: sums.numel()].copy_(sums.reshape(-1))
+    bucket.student_view[: sums.numel()].mul_(rows)
     bucket.pack_loss_grads()
     bucket.all_reduce_mean()
     ops.trace("step_out")
