@@ -760,7 +760,10 @@ class BASDLoss(nn.Module):
                 tail = self._selector_stream(main.device, 2)
                 tail.wait_stream(side)
                 tail.wait_stream(side2)
-                _record_stream(spectra, tail)
+                # only what the tail reads needs marking (every marked block costs an event when it is freed)
+                _record_stream([spectra.get("t_ts"), spectra.get("s_ts"), spectra["ranks_dev"],
+                                spectra.get("t_stack"), spectra.get("t_colnorm"), spectra.get("s_stack"),
+                                spectra.get("s_colnorm")], tail)
                 spectra["student_stream"] = None
                 with torch.cuda.stream(tail):
                     sel._angles_from_spectra(spectra, keys, ranks_host=ranks)
