@@ -123,15 +123,25 @@ def _record_stream(obj, stream) -> None:
             _record_stream(getattr(obj, name), stream)
 
 
+def ctx_zero(ctx, like: torch.Tensor):
+    if ctx.zero_shape is None or not ctx.needs_input_grad[3]:
+        return None
+    return torch.zeros(ctx.zero_shape[0], device=like.device, dtype=ctx.zero_shape[1])
+
+
 class _ProcrustesLayers(torch.autograd.Function):
-    """(mix (E, L), has_cls, eager, teachers, attns, *students) -> per-layer loss (E,).
+    """(mix (E, L), has_cls, eager, zero_param, teachers, attns, *students) -> per-layer loss (E,).
+
+    ``zero_param``: a parameter whose gradient through this loss is identically zero but must still be delivered
+    as zeros (the temperatures with ONE teacher layer: softmax over a single logit); backward hands it zeros
+    directly instead of pushing zeros through softmax / division / softplus nodes.
 
     ``eager``: queue the student-token gradient kernels (for a unit upstream gradient) right behind the forward
     kernels.  The gradient is linear in the upstream scalar, so backward only scales -- used where the caller is
     about to block on a read-back anyway, which takes the gradient launches off the host's critical path."""
 
     @staticmethod
-    def forward(ctx, mix, has_cls, eager, teachers, attns, *students):
+    def forward(ctx, mix, has_cls, eager, zero_param, teachers, attns, *students):
         need_bwd = any(s.requires_grad for s in students)
         # one teacher layer: softmax over one logit is constant, d loss / d mix is exactly 0
         need_mix = bool(mix.requires_grad and mix.shape[1] > 1)
@@ -142,6 +152,7 @@ class _ProcrustesLayers(torch.autograd.Function):
         ctx.save_for_backward(*students)
         ctx.need_mix = need_mix
         ctx.mix_shape = tuple(mix.shape)
+        ctx.zero_shape = None if zero_param is None else (tuple(zero_param.shape), zero_param.dtype)
         ctx.unit_grads = None
         if eager and need_bwd and not need_mix and pc.k_prime is not None:
             ones = torch.ones((len(students),), device=pc.loss_b.device, dtype=torch.float32)
@@ -150,13 +161,14 @@ class _ProcrustesLayers(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_layers):
+        ops.trace("bwd_procrustes_in")
         students = ctx.saved_tensors
         pc = ctx.pc
         g_mix = None
         if pc.k_prime is None:
             if ctx.needs_input_grad[0]:
                 g_mix = torch.zeros(ctx.mix_shape, device=grad_layers.device)
-            return (g_mix, None, None, None, None) + (None,) * ctx.n_students
+            return (g_mix, None, None, ctx_zero(ctx, grad_layers), None, None) + (None,) * ctx.n_students
         if ctx.need_mix:
             kt, tnorm2 = ops.procrustes_teacher_factor(pc)
             grads, gomega = ops.procrustes_student_grads(list(students), pc, grad_layers, tnorm2)
@@ -169,9 +181,10 @@ class _ProcrustesLayers(torch.autograd.Function):
                 grads = ops.procrustes_student_grads(list(students), pc, grad_layers)
             if ctx.needs_input_grad[0]:
                 g_mix = torch.zeros(ctx.mix_shape, device=grad_layers.device)
-        grads = [g.to(s.dtype) if ctx.needs_input_grad[5 + i] else None
+        grads = [g.to(s.dtype) if ctx.needs_input_grad[6 + i] else None
                  for i, (g, s) in enumerate(zip(grads, students))]
-        return (g_mix, None, None, None, None, *grads)
+        ops.trace("bwd_procrustes_out")
+        return (g_mix, None, None, ctx_zero(ctx, grad_layers), None, None, *grads)
 
 
 class _UWSOCombine(torch.autograd.Function):
@@ -193,6 +206,7 @@ class _UWSOCombine(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        ops.trace("bwd_uwso_in")
         (w,) = ctx.saved_tensors
         gw = g * w
         return gw[0], (gw[1] / ctx.n_layers).to(ctx.geo_dtype).expand(ctx.n_layers)
@@ -241,7 +255,7 @@ def geometric_relational_loss(
     if teacher_tokens.requires_grad or teacher_attn.requires_grad:
         raise NotImplementedError("gradients w.r.t. teacher tokens / attention are not implemented yet")
     mix = torch.ones((1, 1), device=student_tokens.device, dtype=torch.float32)
-    return _ProcrustesLayers.apply(mix, bool(has_cls_token), False, [teacher_tokens], [teacher_attn], student_tokens)[0]
+    return _ProcrustesLayers.apply(mix, bool(has_cls_token), False, None, [teacher_tokens], [teacher_attn], student_tokens)[0]
 
 
 # --------------------------------------------------------------------------- #
@@ -738,10 +752,10 @@ class BASDLoss(nn.Module):
                 spectra = sel._spectra_async(students, teachers, student_stream=side2)
             ops.trace("chains_queued")
             ce_loss = self.base_criterion(student_output, targets)     # queued behind the chains' first launches
-            tau = sel.temperatures.float()
-            mix = torch.softmax(torch.zeros((len(students), 1), device=tau.device) / tau.unsqueeze(1), dim=1)
-            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), True, teachers, attns,
-                                                 *students)
+            # softmax over ONE logit: the mixing weights are exactly 1 and d loss / d temperature exactly 0
+            mix = ops._device_consts((1.0,) * len(students), torch.float32, main.device).view(-1, 1)
+            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), True, sel.log_temperatures,
+                                                 teachers, attns, *students)
             ops.trace("procrustes_queued")
 
             def selector_tail():
@@ -771,7 +785,7 @@ class BASDLoss(nn.Module):
             selector_tail = None
             ce_loss = self.base_criterion(student_output, targets)
             mix = sel.mixing_weights(students, keys, teachers)
-            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), False, teachers, attns,
+            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), False, None, teachers, attns,
                                                  *students)
         total = _UWSOCombine.apply(ce_loss, geo_layers)
         self.last_components = {"ce": ce_loss.detach(), "geo_layers": geo_layers.detach(), "mix": mix.detach()}
