@@ -212,6 +212,52 @@ class _UWSOCombine(torch.autograd.Function):
         return gw[0], (gw[1] / ctx.n_layers).to(ctx.geo_dtype).expand(ctx.n_layers)
 
 
+class _SingleTeacherTotal(torch.autograd.Function):
+    """(ce, has_cls, zero_param, teachers, attns, *students) -> (total, geo_layers): the Procrustes loss of every
+    extraction layer against ONE teacher layer (mixing weights exactly 1) and its UW-SO combination with the base
+    loss, as a single autograd node.  The student gradients for a unit upstream gradient are queued by forward
+    (see ``_ProcrustesLayers``); backward is one small product for the weights and one scaling per layer."""
+
+    @staticmethod
+    def forward(ctx, ce, has_cls, zero_param, teachers, attns, *students):
+        E = len(students)
+        need_bwd = any(s.requires_grad for s in students)
+        mix = ops._device_consts((1.0,) * E, torch.float32, ce.device).view(-1, 1)
+        pc = ops.procrustes_forward(list(students), teachers, attns, mix, has_cls, need_backward=need_bwd,
+                                    need_mix_grad=False)
+        geo_layers = pc.loss_b.mean(dim=1)
+        ctx.unit_grads = None
+        if need_bwd and pc.k_prime is not None:
+            ones = ops._device_consts((1.0,) * E, torch.float32, ce.device)
+            ctx.unit_grads = ops.procrustes_student_grads(list(students), pc, ones)
+        # UW-SO (combined.py:78-85) on the detached values
+        vals = torch.stack([ce.detach(), geo_layers.mean().to(ce.dtype)])
+        inv = 1.0 / vals.clamp(min=torch.finfo(ce.dtype).eps)
+        w = inv / inv.sum()
+        ctx.save_for_backward(w)
+        ctx.n_students = E
+        ctx.dtypes = [s.dtype for s in students]
+        ctx.zero_shape = None if zero_param is None else (tuple(zero_param.shape), zero_param.dtype)
+        ctx.mark_non_differentiable(geo_layers)
+        return (w * vals).sum(), geo_layers
+
+    @staticmethod
+    def backward(ctx, g, _g_geo):
+        ops.trace("bwd_total_in")
+        (w,) = ctx.saved_tensors
+        gw = g * w
+        grads = [None] * ctx.n_students
+        if ctx.unit_grads is not None:
+            scale = gw[1] / ctx.n_students
+            grads = [(u * scale).to(dt) if ctx.needs_input_grad[5 + i] else None
+                     for i, (u, dt) in enumerate(zip(ctx.unit_grads, ctx.dtypes))]
+        zero = None
+        if ctx.zero_shape is not None and ctx.needs_input_grad[2]:
+            zero = torch.zeros(ctx.zero_shape[0], device=g.device, dtype=ctx.zero_shape[1])
+        ops.trace("bwd_total_out")
+        return (gw[0] if ctx.needs_input_grad[0] else None, None, zero, None, None, *grads)
+
+
 class _GrassmannDistance(torch.autograd.Function):
     """(selector, keys, teachers, *students) -> d_grass_sq (E, L), differentiable w.r.t. the student tokens
     (reference layer_selector.py:86-105; the backward is the eigenvector-perturbation route)."""
@@ -754,8 +800,8 @@ class BASDLoss(nn.Module):
             ce_loss = self.base_criterion(student_output, targets)     # queued behind the chains' first launches
             # softmax over ONE logit: the mixing weights are exactly 1 and d loss / d temperature exactly 0
             mix = ops._device_consts((1.0,) * len(students), torch.float32, main.device).view(-1, 1)
-            geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), True, sel.log_temperatures,
-                                                 teachers, attns, *students)
+            total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
+                                                          sel.log_temperatures, teachers, attns, *students)
             ops.trace("procrustes_queued")
 
             def selector_tail():
@@ -787,7 +833,7 @@ class BASDLoss(nn.Module):
             mix = sel.mixing_weights(students, keys, teachers)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), False, None, teachers, attns,
                                                  *students)
-        total = _UWSOCombine.apply(ce_loss, geo_layers)
+            total = _UWSOCombine.apply(ce_loss, geo_layers)
         self.last_components = {"ce": ce_loss.detach(), "geo_layers": geo_layers.detach(), "mix": mix.detach()}
         ops.trace("combine_queued")
         if selector_tail is not None:
