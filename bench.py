@@ -4,6 +4,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the second form itself, as a
+child process, before this process has made any GPU call (a process that has touched the GPU is never re-exec'd).
+`--launch-check` rehearses that launch path on the CPU: the workers form a gloo group, all-reduce the real
+gradient bucket once and exit without initialising HIP.
+
 One step = the loss hot path on one synthetic minibatch per GPU: BASDLoss forward (selector ranks /
 subspaces / principal angles, attention-weighted Procrustes loss, CE, UW-SO) + backward to the student
 tokens and logits + (N > 1) RCCL all-reduce of a DeiT-S-sized fp32 gradient buffer (22.05 M parameters
@@ -15,6 +20,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 from types import SimpleNamespace
@@ -80,15 +88,19 @@ def one_step(mod, inp, leaves, logits, bucket):
     grads = [leaves[l].grad for l in mod.token_layers]
     rows = grads[0].shape[0] * grads[0].shape[1]
     sums = ops.column_means(grads)                      # (E, D) means over the B * N token rows
+    bucket.next_slot()                  # ring of two: joins the all-reduce queued on this slot two steps ago
     bucket.student_view[: sums.numel()].copy_(sums.reshape(-1))
     bucket.student_view[: sums.numel()].mul_(rows)
     bucket.pack_loss_grads()            # + the 4 selector temperatures the reference forgets to reduce
-    bucket.all_reduce_mean()            # RCCL over xGMI; no-op at world size 1
+    # RCCL over xGMI on the communicator's own stream: it runs underneath the next step's forward (whose teacher /
+    # selector side does not depend on the optimizer step); no-op at world size 1
+    bucket.all_reduce_mean(async_op=True)
     return loss
 
 
-def cpu_baseline(cfg: str, shape: synth.LossShape, sample_batch: int) -> dict:
-    """The CPU oracle (restatement of the reference, pinned by tests/golden) on a bounded sample."""
+def cpu_baseline(cfg: str, shape: synth.LossShape, sample_batch: int, repeats: int = 3) -> dict:
+    """The CPU oracle (restatement of the reference, pinned by tests/golden) on a bounded sample of the same
+    workload: one warm-up step, then the median of `repeats` forward+backward steps."""
     from oracle import basd_oracle as O
     # LAPACK's SVD does not scale past a few cores (128 threads are SLOWER than 16 on the GPU box's host):
     # use the one-GPU CPU share
@@ -98,17 +110,72 @@ def cpu_baseline(cfg: str, shape: synth.LossShape, sample_batch: int) -> dict:
     state = O.SelectorState.create(shape.points, shape.d_s, shape.d_t)
     crit = torch.nn.CrossEntropyLoss(label_smoothing=LABEL_SMOOTHING[cfg])
     inp = synth.make_inputs(shape, 1234, batch=sample_batch)
-    for v in inp.student.values():
-        v.requires_grad_(True)
-    inp.logits.requires_grad_(True)
     layers = O.extraction_layers(shape.depth, shape.points)
-    t0 = time.perf_counter()
-    loss, _ = O.basd_forward(state, crit, layers, shape.n_s, shape.has_cls, inp.logits, inp.targets, inp.student,
-                             inp.teacher, inp.attn)
-    loss.backward()
-    dt = time.perf_counter() - t0
+    times = []
+    for it in range(repeats + 1):
+        for v in inp.student.values():
+            v.grad = None
+            v.requires_grad_(True)
+        inp.logits.grad = None
+        inp.logits.requires_grad_(True)
+        t0 = time.perf_counter()
+        loss, _ = O.basd_forward(state, crit, layers, shape.n_s, shape.has_cls, inp.logits, inp.targets, inp.student,
+                                 inp.teacher, inp.attn)
+        loss.backward()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     return {"value": sample_batch / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 step (fwd+bwd) of the CPU oracle at {cfg} shapes with batch {sample_batch}: {dt:.1f} s"}
+            "sample": f"CPU oracle, {cfg} shapes at batch {sample_batch}: 1 warm-up + median of {repeats} "
+                      f"forward+backward steps = {dt:.2f} s/step ({', '.join(f'{t:.2f}' for t in times)})"}
+
+
+def _free_port() -> int:
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_workers(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this file under torch.distributed.run as a
+    CHILD process and hand its exit code back.  Nothing in this (parent) process has initialised HIP: importing
+    torch and this repo's modules does not, and the library is only dlopen'ed by the first kernel call."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC for RCCL across processes on this host
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args, rank: int, world: int) -> None:
+    """CPU rehearsal of the N > 1 launch path (no GPU call anywhere): gloo group, the real-size gradient bucket
+    (student parameters + the selector temperatures) all-reduced once, max-over-ranks time, one JSON line."""
+    dist.init_process_group("gloo")
+    shape = synth.CONFIGS[args.config]
+    mod = build(shape, args.config, "cpu")
+    bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), "cpu", slots=2)
+    bucket.student_view.fill_(float(rank + 1))
+    mod.layer_selector.log_temperatures.grad = torch.full((shape.points,), 10.0 * (rank + 1))
+    bucket.pack_loss_grads()
+    dist.barrier()
+    t0 = time.perf_counter()
+    bucket.all_reduce_mean(async_op=True)
+    bucket.wait(all_slots=True)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    expect = sum(range(1, world + 1)) / world
+    ok = bool(torch.allclose(bucket.student_view[:16], torch.full((16,), expect))
+              and torch.allclose(bucket.buffer[-shape.points:], torch.full((shape.points,), 10.0 * expect)))
+    if rank == 0:
+        print(json.dumps({"launch_check": ok, "n_gpus": world, "backend": "gloo",
+                          "grad_allreduce_bytes": int(bucket.buffer.numel() * 4),
+                          "allreduce_ms_max_over_ranks": 1e3 * float(t.item()),
+                          "hip_initialised": bool(torch.cuda.is_initialized())}))
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
 
 
 def main() -> None:
@@ -121,14 +188,21 @@ def main() -> None:
     ap.add_argument("--contiguous", action="store_true", help="contiguous inputs instead of the callers' strided views")
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point time table to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=64)
+    ap.add_argument("--cpu-sample-batch", type=int, default=32)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="CPU rehearsal of the N > 1 launch: gloo group + one all-reduce of the gradient bucket, no GPU call")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_workers(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_check:
+        launch_check(args, rank, world)
+        return
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if world > 1:
@@ -142,7 +216,7 @@ def main() -> None:
                             attn_on_device=shape.layers_t > 1)
     leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
     logits = inp.logits.detach().requires_grad_(True)
-    bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), device)
+    bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), device, slots=2)
     multi_layer = shape.layers_t > 1
 
     def step():
@@ -150,6 +224,8 @@ def main() -> None:
 
     for _ in range(args.warmup):
         loss = step()
+    mod.layer_selector.finish_pending()       # deferred selector tail of the last warm-up step: outside the timing
+    bucket.wait(all_slots=True)
     # dominant kernel: tridiag_kernel (Householder tridiagonalisation of the selector's Gram matrices; the
     # entry point basd_tridiag is exactly one launch).  HIP events are recorded on the stream it is queued on.
     dominant = "basd_tridiag" if ops.EIG_SOLVER == "tridiag" else "basd_jacobi_onesided"
@@ -161,6 +237,8 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    mod.layer_selector.finish_pending()       # ... and that of the last timed step: inside
+    bucket.wait(all_slots=True)               # the all-reduces still queued on the communicator's stream
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -239,7 +317,10 @@ def main() -> None:
                 "teacher_tokens": [shape.layers_t, batch, shape.n_t, shape.d_t],
                 "layout": "contiguous" if args.contiguous else "strided (CLS-sliced / channel-major views)",
                 "backward": True,
-                "grad_allreduce_bytes": int(bucket.buffer.numel() * 4) if world > 1 else 0,
+                "grad_allreduce_bytes": int(bucket.buffer.numel() * 4),
+                "grad_allreduce": "RCCL all-reduce (mean) per step on the communicator's stream" if world > 1
+                else "none at world size 1 (bucket packed, nothing to exchange)",
+                "rank_readback": "sync" if mod.sync_ranks else "deferred",
                 "parallelism": f"dp{world}",
             },
             "path_hbm": {

@@ -256,12 +256,16 @@ def test_bf16_inputs_cfg5_shapes():
         assert ((g - r).norm() / r.norm()).item() < 1e-2       # the gradient itself is rounded to bf16
 
 
-def test_rank_zero_raises_like_the_reference():
+@pytest.mark.parametrize("sync_ranks", [True, False])
+def test_rank_zero_raises_like_the_reference(sync_ranks):
     """A teacher whose projected Gram has a flat spectrum has Marchenko-Pastur rank 0 (no eigenvalue exceeds
     median * (1 + sqrt(q))^2); the reference then produces NaN mixing weights and torch.linalg.svd raises
-    LinAlgError.  Same class here, and the oracle agrees on the rank."""
+    LinAlgError.  Same class here, and the oracle agrees on the rank.
+    ``sync_ranks`` (BASD_RANK_READBACK=sync): raised inside the call, the reference's timing; default (deferred
+    read-back, one teacher layer): raised by the first reader of ``subspace_ranks`` or by the next forward."""
     shape = synth.LossShape("flat", 4, 16, 32, 12, 16, 48, 1, 1, False, 10)
     mod = _module(shape, 0.0)
+    mod.sync_ranks = sync_ranks
     gen = torch.Generator().manual_seed(1)
     B = 8
     q, _ = torch.linalg.qr(torch.randn(B * 16, 48, generator=gen))      # orthonormal columns: T^T T = I
@@ -272,8 +276,16 @@ def test_rank_zero_raises_like_the_reference():
     attn = {0: (torch.ones(B, 1, 16, 16) / 16).to(DEV)}
     logits = torch.randn(B, 10, generator=gen).to(DEV)
     targets = torch.randint(0, 10, (B,), generator=gen).to(DEV)
-    with pytest.raises(torch.linalg.LinAlgError):
-        mod(logits, targets, student, teacher, attn)
+    if sync_ranks:
+        with pytest.raises(torch.linalg.LinAlgError):
+            mod(logits, targets, student, teacher, attn)
+    else:
+        loss = mod(logits, targets, student, teacher, attn)        # the Procrustes value does not depend on the rank
+        assert torch.isfinite(loss).item()
+        with pytest.raises(torch.linalg.LinAlgError):
+            mod(logits, targets, student, teacher, attn)           # the previous step's error surfaces here
+        with pytest.raises(torch.linalg.LinAlgError):
+            mod.layer_selector.subspace_ranks                      # ... and this step's on the first read
     assert mod.layer_selector.subspace_ranks == {0: 0}
 
 

@@ -15,11 +15,36 @@ class FlatGradBucket:
     """One contiguous fp32 buffer holding [student gradients | loss-module gradients]; a single
     all-reduce per step over RCCL/xGMI (backend "nccl" on ROCm) or gloo (CPU tests)."""
 
-    def __init__(self, student_numel: int, loss_params: list[torch.nn.Parameter], device) -> None:
+    def __init__(self, student_numel: int, loss_params: list[torch.nn.Parameter], device, slots: int = 1) -> None:
+        """``slots`` > 1: a ring of buffers, so that the all-reduce of step i (queued with ``async_op``) runs on
+        the communicator's stream underneath step i+1 while that step fills the next slot."""
         self.loss_params = list(loss_params)
         self.student_numel = int(student_numel)
         self.extra = sum(p.numel() for p in self.loss_params)
-        self.buffer = torch.zeros(self.student_numel + self.extra, device=device, dtype=torch.float32)
+        self._slots = [torch.zeros(self.student_numel + self.extra, device=device, dtype=torch.float32)
+                       for _ in range(max(1, int(slots)))]
+        self._pending: list = [None] * len(self._slots)
+        self._slot = 0
+
+    @property
+    def buffer(self) -> torch.Tensor:
+        return self._slots[self._slot]
+
+    def next_slot(self) -> None:
+        """Move on to the next buffer of the ring; its previous all-reduce (if still queued) is joined first."""
+        self._slot = (self._slot + 1) % len(self._slots)
+        self.wait()
+
+    def wait(self, all_slots: bool = False) -> None:
+        """Join the all-reduce queued on the current slot (every slot with ``all_slots``): the current stream waits
+        for the collective (RCCL: no host block) and the mean is completed where the backend only sums."""
+        for i in (range(len(self._slots)) if all_slots else (self._slot,)):
+            pending, self._pending[i] = self._pending[i], None
+            if pending is not None:
+                work, divide = pending
+                work.wait()
+                if divide:
+                    self._slots[i].div_(dist.get_world_size())
 
     @property
     def student_view(self) -> torch.Tensor:
@@ -35,16 +60,24 @@ class FlatGradBucket:
                 self.buffer[off:off + n].copy_(p.grad.reshape(-1))
             off += n
 
-    def all_reduce_mean(self) -> None:
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            if dist.get_backend() == "nccl" and getattr(self, "_avg_ok", True):
-                try:
-                    dist.all_reduce(self.buffer, op=dist.ReduceOp.AVG)  # RCCL averages in the reduction
-                    return
-                except (RuntimeError, ValueError):                      # a build without ncclAvg: rejected before launch
-                    self._avg_ok = False
-            dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM)          # gloo (CPU tests) has no AVG
-            self.buffer.div_(dist.get_world_size())
+    def all_reduce_mean(self, async_op: bool = False) -> None:
+        """Mean over ranks of the current slot.  ``async_op``: only queued (on the communicator's own stream, behind
+        the work already on the current stream); ``wait`` / ``next_slot`` join it."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        work = divide = None
+        if dist.get_backend() == "nccl" and getattr(self, "_avg_ok", True):
+            try:
+                work = dist.all_reduce(self.buffer, op=dist.ReduceOp.AVG, async_op=True)   # RCCL averages in the reduction
+                divide = False
+            except (RuntimeError, ValueError):                      # a build without ncclAvg: rejected before launch
+                self._avg_ok = False
+        if work is None:
+            work = dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, async_op=True)       # gloo (CPU tests) has no AVG
+            divide = True
+        self._pending[self._slot] = (work, divide)
+        if not async_op:
+            self.wait()
 
     def unpack_loss_grads(self) -> None:
         off = self.student_numel

@@ -311,7 +311,8 @@ class GrassmannianLayerSelector(nn.Module):
     def __init__(self, num_extraction_points: int, student_dim: int, teacher_dim: int):
         super().__init__()
         self.student_dim = student_dim
-        self.subspace_ranks: dict[int, int] = {}
+        self._subspace_ranks: dict[int, int] = {}
+        self._pending_tail = None          # deferred rank read-back + selector tail of the latest forward
 
         # Same global-RNG consumption order as the reference (proj_s, then proj_t), on CPU.
         proj_s = torch.empty(student_dim, student_dim)
@@ -326,6 +327,26 @@ class GrassmannianLayerSelector(nn.Module):
     @property
     def temperatures(self) -> torch.Tensor:
         return F.softplus(self.log_temperatures)
+
+    # ``subspace_ranks`` is the reference's public dict (layer_selector.py:48,74), refreshed by every forward.
+    # With one teacher layer the ranks do not feed the loss, so ``BASDLoss.forward`` does not wait for them: the
+    # read-back (and the rank-0 error the reference raises inside forward) is completed by the next forward, or
+    # by whoever reads this attribute first -- reading it blocks exactly like the reference's ``.item()`` does.
+    @property
+    def subspace_ranks(self) -> dict[int, int]:
+        self.finish_pending()
+        return self._subspace_ranks
+
+    @subspace_ranks.setter
+    def subspace_ranks(self, value: dict[int, int]) -> None:
+        self._subspace_ranks = value
+
+    def finish_pending(self) -> None:
+        """Complete the deferred part of the latest forward: wait for its rank kernel, refresh
+        ``subspace_ranks``, raise what the reference would have raised, queue the rest of the selector."""
+        pending, self._pending_tail = self._pending_tail, None
+        if pending is not None:
+            pending()
 
     # ---- teacher side: ranks + subspaces -------------------------------------------------
     @torch.no_grad()
@@ -369,8 +390,9 @@ class GrassmannianLayerSelector(nn.Module):
         g_u, _, M, _ = self._teacher_grams(teachers)
         vals_u = _eigenvalues_desc(g_u)
         ranks_dev = ops.mp_rank_device(vals_u, M, self.student_dim, cap=self.student_dim - 1)   # :74
+        self.finish_pending()
         for k, r in zip(keys, ranks_dev.tolist()):
-            self.subspace_ranks[k] = int(r)
+            self._subspace_ranks[k] = int(r)
 
     def _proj_s_transposed(self) -> torch.Tensor:
         """proj_s^T, fp32 contiguous; cached (the buffer only changes on load_state_dict / .to())."""
@@ -463,12 +485,12 @@ class GrassmannianLayerSelector(nn.Module):
         return st
 
     def _pinned_ints(self, slot: str, count: int) -> torch.Tensor:
-        """Pinned int32 host buffer; two per slot, used alternately, so that a value may still be read one step
-        later while the next step's is being produced."""
+        """Pinned int32 host buffer; a ring of four per slot, so that a value may still be read two steps
+        later (deferred read-back) while the following steps' values are being produced."""
         bufs = self.__dict__.setdefault("_pinned", {})
         flip = self.__dict__.setdefault("_pinned_flip", {})
         idx = flip.get(slot, 0)
-        flip[slot] = idx ^ 1
+        flip[slot] = (idx + 1) % 4
         key = (slot, idx)
         if key not in bufs or bufs[key].numel() != count:
             bufs[key] = torch.empty((count,), dtype=torch.int32, pin_memory=True)
@@ -510,7 +532,7 @@ class GrassmannianLayerSelector(nn.Module):
             raise RuntimeError("basd_tridiag: workgroups sharing a matrix timed out waiting for each other "
                                f"(device oversubscribed?); eigen-solve results are invalid [{host[L:]}]")
         for k, r in zip(keys, ranks):
-            self.subspace_ranks[k] = r
+            self._subspace_ranks[k] = r
         if min(ranks) == 0:
             # reference: 0/0 distance -> NaN weights -> NaN tokens -> torch.linalg.svd raises
             raise torch.linalg.LinAlgError(
@@ -748,6 +770,9 @@ class BASDLoss(nn.Module):
         )
         self.last_components: dict[str, torch.Tensor] = {}
         self._side_streams: dict = {}
+        # When the selector does not feed the loss (one teacher layer) the host need not wait for the ranks
+        # inside forward; BASD_RANK_READBACK=sync restores the reference's timing (read and raise in the call).
+        self.sync_ranks = os.environ.get("BASD_RANK_READBACK", "deferred") == "sync"
 
     def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
         key = (str(device), index)
@@ -755,7 +780,7 @@ class BASDLoss(nn.Module):
             # the teacher chain (0) gates the step's one host read-back (the ranks): high priority, so that its
             # kernels are dispatched ahead of the student chain's (1) and the main stream's when they compete
             mode = os.environ.get("BASD_CHAIN_PRIORITY", "2")
-            prio = -1 if (mode == "1" and index < 2) or (mode == "2" and index == 0) else 0
+            prio = -1 if (mode == "1" and index % 3 < 2) or (mode == "2" and index % 3 == 0) else 0
             self._side_streams[key] = torch.cuda.Stream(device=device, priority=prio)
         return self._side_streams[key]
 
@@ -786,8 +811,13 @@ class BASDLoss(nn.Module):
             # the Procrustes loss does not depend on the selector.  The selector's eigen-solves are latency-
             # bound chains of small launches; run them on a side stream underneath the Procrustes kernels.
             main = torch.cuda.current_stream()
-            side = self._selector_stream(main.device)
-            side2 = self._selector_stream(main.device, 1)
+            # two sets of chain streams, used by alternate steps: with the deferred read-back the chains of
+            # consecutive steps overlap instead of queueing behind each other
+            lane = 0
+            if not self.sync_ranks:
+                lane = self._chain_lane = (getattr(self, "_chain_lane", 1) + 1) % 2
+            side = self._selector_stream(main.device, 3 * lane)
+            side2 = self._selector_stream(main.device, 3 * lane + 1)
             side.wait_stream(main)
             # the borrowed inputs are read on the side streams after this call has returned (the tail of the
             # selector is not joined into the main stream: nothing downstream of it feeds the loss)
@@ -803,21 +833,18 @@ class BASDLoss(nn.Module):
             total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
                                                           sel.log_temperatures, teachers, attns, *students)
             ops.trace("procrustes_queued")
+            tail = self._selector_stream(main.device, 3 * lane + 2)
 
             def selector_tail():
-                # The host reads the ranks here (and raises on rank 0 like the reference); called last so that
-                # everything else of the step is queued before the host blocks.  The rest of the selector
+                # The host reads the ranks here (and raises on rank 0 like the reference).  The rest of the selector
                 # (eigenvectors, principal angles) goes to a third stream: the next step's eigen-solve chains do
                 # not queue behind it, and nothing of it feeds this loss when there is one teacher layer.
-                # (Queuing it one call later, in the window where the host idles waiting for the ranks, was
-                # measured on the same box: the ranks then arrive 0.25 ms later and the step time is unchanged.)
                 if "rank_ready" in spectra:
                     ranks = sel._read_ranks(spectra, keys)              # waits on the rank kernel's event
                 else:
                     with torch.cuda.stream(side):                       # plain read-back behind both chains
                         side.wait_stream(side2)
                         ranks = sel._read_ranks(spectra, keys)
-                tail = self._selector_stream(main.device, 2)
                 tail.wait_stream(side)
                 tail.wait_stream(side2)
                 # only what the tail reads needs marking (every marked block costs an event when it is freed)
@@ -829,6 +856,7 @@ class BASDLoss(nn.Module):
                     sel._angles_from_spectra(spectra, keys, ranks_host=ranks)
         else:
             selector_tail = None
+            sel.finish_pending()
             ce_loss = self.base_criterion(student_output, targets)
             mix = sel.mixing_weights(students, keys, teachers)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), False, None, teachers, attns,
@@ -837,6 +865,17 @@ class BASDLoss(nn.Module):
         self.last_components = {"ce": ce_loss.detach(), "geo_layers": geo_layers.detach(), "mix": mix.detach()}
         ops.trace("combine_queued")
         if selector_tail is not None:
-            selector_tail()
+            if self.sync_ranks:
+                # the reference's timing: ranks read (and rank 0 raised) inside this call; called last so that
+                # everything else of the step is queued before the host blocks
+                sel.finish_pending()
+                selector_tail()
+            else:
+                # deferred: the PREVIOUS step's ranks are read now (its rank kernel finished long ago; if not,
+                # this wait is the back-pressure that keeps the host at most one step ahead), this step's by the
+                # next forward or by the first reader of ``subspace_ranks``
+                previous, sel._pending_tail = sel._pending_tail, selector_tail
+                if previous is not None:
+                    previous()
         ops.trace("fwd_out")
         return total
