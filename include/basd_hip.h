@@ -11,7 +11,7 @@
  *     (pass torch.cuda.current_stream().cuda_stream); scratch buffers are caller-provided;
  *   - return value: 0 = ok, <0 = invalid argument / unsupported shape (BASD_E*), >0 = hipError_t;
  *   - dtype codes: 0 = fp32, 1 = bf16 (inputs only; all arithmetic and outputs are fp32/fp64);
- *   - entry points are re-entrant and keep no global mutable state.
+ *   - entry points are re-entrant and keep no global mutable state (one exception, for tests: basd_tridiag_tuning).
  */
 #ifndef BASD_HIP_H
 #define BASD_HIP_H
@@ -119,12 +119,21 @@ int basd_sort_extract(const float* W, long batch_stride, int rows, int rows_tot,
  * Vt[:k] / S[:k] part of torch.linalg.svd (:36, :92).  d, e, tau: (batch, n); vh: (batch, n, n). */
 long basd_tridiag_workspace_bytes(int n, int batch);
 
-/* `work`: basd_tridiag_workspace_bytes(n, batch) bytes of 16-byte aligned device scratch.  A matrix is shared by
- * up to 8 workgroups that exchange one 16-byte granule per row and step through it; its last 32 bytes hold a
- * status word that is non-zero afterwards if a workgroup gave up waiting for its partners, and a trace of the
- * first give-up (step + 1, row, member | matrix << 8, tag seen, tag wanted). */
+/* `work`: basd_tridiag_workspace_bytes(n, batch) bytes of 16-byte aligned device scratch.
+ * Two stages: the trailing block of order <= 256 is factored in the registers of ONE CU per matrix (n <= 256: the
+ * whole factorisation -- no workgroup waits for another); for n > 256 the first n - 256 steps run with the matrix
+ * shared by up to 16 workgroups that exchange one 16-byte granule per row and step through `work`.  Its last 32
+ * bytes hold a status word that is non-zero afterwards if a workgroup of the shared stage gave up waiting for its
+ * partners, and a trace of the first give-up (step + 1, row, member | matrix << 8, tag seen, tag wanted). */
 int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
                  void* work, hipStream_t stream);
+
+/* Test / tuning hook for basd_tridiag (the only process-wide setting of the library; its defaults come from the
+ * BASD_TRIDIAG_{MEMBERS,PAD,LAG,THREADS,TAIL} environment variables, read ONCE when the library is loaded -- no
+ * entry point calls getenv).  Negative = keep; reset != 0 restores the load-time values first.
+ * members: workgroups per matrix in the shared stage; pad: workgroup-id padding between matrices; lag: member that
+ * sleeps every step; threads: per member; tail: 0 = shared stage for the whole factorisation. */
+int basd_tridiag_tuning(int members, int pad, int lag, int threads, int tail, int reset);
 
 /* All eigenvalues (descending) of the tridiagonals by Sturm-sequence bisection. */
 int basd_tridiag_eigenvalues(const float* d, const float* e, int n, int batch, float* vals_desc, hipStream_t stream);

@@ -105,11 +105,13 @@ def test_centered_grams_multi(dev, B, N, D, dtype):
         assert _rel(out2[i], c.T @ c) < tol
 
 
-@pytest.mark.parametrize("n,rows_dot,rows_tot", [(49, 49, 98), (50, 50, 100), (7, 7, 7), (96, 96, 192), (130, 130, 130)])
-def test_jacobi_lds_invariants(dev, n, rows_dot, rows_tot):
+@pytest.mark.parametrize("n,rows_dot,rows_tot,batch", [
+    (49, 49, 98, 5), (50, 50, 100, 5), (7, 7, 7, 5), (96, 96, 192, 5), (130, 130, 130, 5),
+    # large batches of small stacked matrices take the 4-lanes-per-pair kernel
+    (49, 49, 98, 300), (31, 31, 62, 260), (64, 64, 128, 256), (9, 9, 18, 256), (36, 25, 61, 257)])
+def test_jacobi_lds_invariants(dev, n, rows_dot, rows_tot, batch):
     from basd_amd import ops
     g = torch.Generator().manual_seed(n)
-    batch = 5
     w0 = torch.randn(batch, n, rows_tot, generator=g)
     w0[:, :, :rows_dot] *= torch.logspace(0, -3, n).view(1, n, 1)       # spread the spectrum
     W = w0.clone().to(dev)
@@ -199,8 +201,19 @@ def test_resample_matches_interpolate(dev):
         assert (x.grad - ref_in.grad).abs().max() < 1e-6 * ref_in.grad.abs().max()
 
 
-@pytest.mark.parametrize("n", [384, 100, 45, 33])
-def test_tridiag_member_count_is_invisible(dev, n, monkeypatch):
+@pytest.fixture
+def tuning():
+    """basd_tridiag_tuning(members, pad, lag, threads, tail): test hook of the library; restored afterwards."""
+    from basd_amd import _lib
+
+    def set_(members=-1, pad=-1, lag=-1, threads=-1, tail=-1, reset=0):
+        _lib.call("basd_tridiag_tuning", members, pad, lag, threads, tail, reset)
+    yield set_
+    _lib.call("basd_tridiag_tuning", -1, -1, -1, -1, -1, 1)
+
+
+@pytest.mark.parametrize("n", [384, 768, 100, 45, 33])
+def test_tridiag_member_count_is_invisible(dev, n, tuning):
     """The workgroups sharing a matrix exchange rows of identical arithmetic: d, e, tau and the reflectors are
     bit-identical whatever the member count (vector+full, vector+ragged and scalar kernels)."""
     from basd_amd import ops
@@ -209,9 +222,9 @@ def test_tridiag_member_count_is_invisible(dev, n, monkeypatch):
     G0 = (x.transpose(1, 2) @ x).to(dev)
     outs = []
     for members in ("1", "2", "5", "16", "16x"):
-        monkeypatch.setenv("BASD_TRIDIAG_MEMBERS", members.rstrip("x"))
+        tuning(members=int(members.rstrip("x")))
         if members.endswith("x"):       # ids of one matrix no longer agree mod 8: its members sit on different XCDs
-            monkeypatch.setenv("BASD_TRIDIAG_PAD", "3")
+            tuning(pad=3)
         ts = ops.tridiag_eigenvalues(G0.clone())
         assert int(ts.err[0].item()) == 0
         outs.append(ts)
@@ -223,8 +236,31 @@ def test_tridiag_member_count_is_invisible(dev, n, monkeypatch):
     assert ((outs[-1].vals.double().cpu() - ref).abs().max(dim=1).values / ref[:, 0]).max() < 3e-6
 
 
+@pytest.mark.parametrize("n", [384, 256, 257, 300, 192, 768, 64, 7])
+def test_tridiag_tail_stage_reconstructs_the_matrix(dev, n, tuning):
+    """The register-resident tail stage (whole factorisation for n <= 256, last 256 steps above): Q T Q^T gives the
+    matrix back, Q is orthogonal, and T has the spectrum of the all-shared-stage factorisation."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(31 * n)
+    x = torch.randn(3, 3 * n + 5, n, generator=g)
+    G0 = (x.transpose(1, 2) @ x).to(dev)
+    ts = ops.tridiag_eigenvalues(G0.clone())
+    assert int(ts.err[0].item()) == 0
+    eye = torch.eye(n, device=dev).repeat(3, 1, 1).contiguous()
+    Qt = ops.tridiag_apply_q(ts, eye, transpose=False).double()        # row i = Q e_i
+    T = torch.diag_embed(ts.d.double()) + torch.diag_embed(ts.e[:, :n - 1].double(), 1) + \
+        torch.diag_embed(ts.e[:, :n - 1].double(), -1)
+    rec = Qt.transpose(1, 2) @ T @ Qt
+    scale = G0.double().abs().amax(dim=(1, 2), keepdim=True)
+    assert ((rec - G0.double()).abs() / scale).max() < 2e-5
+    assert (Qt @ Qt.transpose(1, 2) - torch.eye(n, device=dev, dtype=torch.float64)).abs().max() < 2e-5
+    tuning(tail=0)
+    ref = ops.tridiag_eigenvalues(G0.clone())
+    assert ((ts.vals - ref.vals).abs().amax(dim=1) / ref.vals[:, 0]).max() < 3e-6
+
+
 @pytest.mark.parametrize("lag", ["0", "3", "11"])
-def test_tridiag_lagging_member(dev, monkeypatch, lag):
+def test_tridiag_lagging_member(dev, tuning, lag):
     """A member that is slower than the others every step (test hook) -- early on, in the middle, or the one that
     lives to the end -- must neither be lost (it only ever needs granules of members that wait for it) nor
     change a bit of the result.  (Regression: members whose rows were all reduced used to stay in the loop,
@@ -234,16 +270,16 @@ def test_tridiag_lagging_member(dev, monkeypatch, lag):
     n = 384
     x = torch.randn(2, 4 * n, n, generator=g)
     G0 = (x.transpose(1, 2) @ x).to(dev)
-    monkeypatch.setenv("BASD_TRIDIAG_MEMBERS", "12")
+    tuning(members=12, tail=0)                          # the shared stage for the WHOLE factorisation
     ref = ops.tridiag_eigenvalues(G0.clone())           # same configuration, nobody lagging
-    monkeypatch.setenv("BASD_TRIDIAG_LAG", lag)
+    tuning(lag=int(lag))
     ts = ops.tridiag_eigenvalues(G0.clone())
     assert ts.err.tolist()[0] == 0, ts.err.tolist()
     for name in ("d", "e", "tau", "vh"):
         assert torch.equal(getattr(ts, name), getattr(ref, name)), name
 
 
-def test_tridiag_members_under_uneven_load(dev, monkeypatch):
+def test_tridiag_members_under_uneven_load(dev, tuning):
     """Hand-off stress: two shared-matrix factorisations on two streams while a third stream keeps the chip busy
     with long MFMA workgroups (the situation of a training step).  Every launch must reproduce the idle-chip
     result bit for bit and leave its status word at zero."""

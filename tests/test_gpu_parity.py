@@ -316,3 +316,71 @@ def test_selector_forward_api_materialises_mixed_tensors(golden):
             m, a = sel._mix_for_student_layer(i, inp.student[l], keys, tok, att, sub, spw)
             np.testing.assert_allclose(m[:, :5, :7].cpu().numpy(), g[f"mixed_{l}_slice"], rtol=2e-3, atol=2e-4)
             np.testing.assert_allclose(a[:, :, 0, 1:].cpu().numpy(), g[f"attn_{l}_cls_row"], rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["vit", "cnn", "vit_same"])
+def test_estimate_ranks_golden(golden, tag):
+    """GrassmannianLayerSelector._estimate_ranks (layer_selector.py:69-74) by itself: ``subspace_ranks`` against the
+    ranks the imported reference produced on the same teacher tensors (exact)."""
+    g = golden("full_small.npz")
+    shape, seed = S.SMALL[tag]
+    mod = _module(shape, 0.01)
+    inp = synth.make_inputs(shape, seed, device=DEV)
+    sel = mod.layer_selector
+    assert sel.subspace_ranks == {}
+    sel._estimate_ranks(inp.teacher)
+    assert [sel.subspace_ranks[k] for k in sorted(inp.teacher)] == list(g[f"{tag}_ranks"])
+
+
+def test_estimate_ranks_cfg4_shapes(golden):
+    """... and at cfg-4 shapes (24 ViT-L layers, batch 4), strided CLS-sliced views."""
+    g = golden("baseline_scalars.npz")
+    shape = synth.CONFIGS["cfg4"]
+    mod = _module(shape, 0.001)
+    inp = synth.make_inputs(shape, 1234, batch=4, device=DEV, strided=True)
+    mod.layer_selector._estimate_ranks(inp.teacher)
+    assert [mod.layer_selector.subspace_ranks[k] for k in sorted(inp.teacher)] == list(g["cfg4_s1234_b4_ranks"])
+
+
+@pytest.mark.parametrize("name,dtype", [("cfg4", torch.float32), ("cfg5", torch.bfloat16)])
+def test_full_batch_properties(name, dtype):
+    """BASELINE.json configs[3] (B=128, 24 teacher layers: the block Jacobi path on 512 stacked 392 x 196 cores) and
+    configs[4] (B=64, 576 student tokens, bf16 features) at FULL batch.  The oracle needs minutes there, so the
+    checks are the size-independent properties of the path: finite loss, per-sample Procrustes loss >= 0 (it is a
+    squared Bures-Wasserstein distance), total = harmonic mean of CE and geo (UW-SO, combined.py:78-85), mixing
+    weights on the simplex, every SVD converged below the sweep cap, eigen-solver status words clean, gradients
+    finite and of the inputs' dtype."""
+    shape = synth.CONFIGS[name]
+    mod = _module(shape, 0.001)
+    inp = synth.make_inputs(shape, 1234, device=DEV, dtype=dtype, strided=True, attn_on_device=shape.layers_t > 1)
+    leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
+    logits = inp.logits.requires_grad_(True)
+    loss = mod(logits, inp.targets, leaves, inp.teacher, inp.attn)
+    loss.backward()
+    ranks = mod.layer_selector.subspace_ranks            # completes the read-back; raises on a give-up / rank 0
+    assert len(ranks) == shape.layers_t and min(ranks.values()) >= 1
+    assert max(ranks.values()) <= shape.d_s - 1
+    comp = mod.last_components
+    ce, geo = comp["ce"].item(), comp["geo_layers"].mean().item()
+    assert np.isfinite(loss.item()) and geo > 0
+    assert abs(loss.item() - 2 * ce * geo / (ce + geo)) < 1e-4 * loss.item()
+    mix = comp["mix"].cpu().numpy()
+    assert mix.shape == (shape.points, shape.layers_t) and (mix >= 0).all()
+    np.testing.assert_allclose(mix.sum(axis=1), 1.0, rtol=1e-5)
+    for l in mod.token_layers:
+        gl = leaves[l].grad
+        assert gl.dtype == dtype and torch.isfinite(gl.float()).all().item() and gl.float().norm().item() > 0
+    if shape.layers_t > 1:
+        gt = mod.layer_selector.log_temperatures.grad
+        assert torch.isfinite(gt).all().item()
+    # the Procrustes cores once more, with the sweep counts
+    students = [leaves[l].detach() for l in mod.token_layers]
+    keys = sorted(inp.teacher)
+    pc = ops.procrustes_forward(students, [inp.teacher[k] for k in keys], [inp.attn[k] for k in keys],
+                                comp["mix"].float(), shape.has_cls, need_backward=False, want_sweeps=True)
+    lb = pc.loss_b.cpu().numpy()
+    scale = (pc.tr_s + pc.tr_t).cpu().numpy()
+    assert np.isfinite(lb).all() and (lb >= -2e-5 * scale).all()
+    np.testing.assert_allclose(lb.mean(axis=1), comp["geo_layers"].cpu().numpy(), rtol=1e-5)
+    if pc.sweeps is not None and int(pc.sweeps.max()) > 0:
+        assert int(pc.sweeps.max()) < ops.MAX_SWEEPS

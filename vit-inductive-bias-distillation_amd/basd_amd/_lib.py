@@ -30,6 +30,7 @@ SIGNATURES = {
     "basd_jacobi_onesided": [vp, i64, i32, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp],
     "basd_sort_extract": [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
     "basd_tridiag_workspace_bytes": [i32, i32],
+    "basd_tridiag_tuning": [i32, i32, i32, i32, i32, i32],
     "basd_tridiag": [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp],
     "basd_tridiag_eigenvalues": [vp, vp, i32, i32, vp, vp],
     "basd_tridiag_apply_q": [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp],

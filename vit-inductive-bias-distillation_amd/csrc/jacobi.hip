@@ -67,8 +67,14 @@ __device__ __forceinline__ Rot make_rotation(float alpha, float beta, float gamm
 
 template <int LPP>
 __device__ __forceinline__ float pair_allsum(float x) {
-    static_assert(LPP == 16 || LPP == 64, "a pair is owned by one DPP row or one wave");
-    return LPP == 16 ? row16_allsum(x) : wave64_allsum(x);
+    static_assert(LPP == 4 || LPP == 16 || LPP == 64, "a pair is owned by one quad, one DPP row or one wave");
+    if constexpr (LPP == 4) {
+        x += dpp_get<0xB1>(x);    // quad_perm [1,0,3,2]
+        x += dpp_get<0x4E>(x);    // quad_perm [2,3,0,1]
+        return x;
+    } else {
+        return LPP == 16 ? row16_allsum(x) : wave64_allsum(x);
+    }
 }
 
 // Orthogonalise LDS columns p and q with one DPP row of 16 lanes (gl = lane index in the row).
@@ -142,15 +148,21 @@ __device__ __forceinline__ int lds_row(int r, int rows_dot) {
 }
 
 // ---------------------------------------------------------------------------
-// LDS-resident solver.  grid = batch, block = multiple of 64; a pair = one DPP row of 16 lanes.
-// DOT == EPL: rows_dot == rows_tot <= 16 EPL.   DOT < EPL: rows_dot <= 16 DOT, rows_tot - rows_dot <= 16 (EPL - DOT).
+// LDS-resident solver.  grid = batch, block = multiple of 64; a pair = LPP adjacent lanes (one DPP row of 16, or one
+// quad).  DOT == EPL: rows_dot == rows_tot <= LPP EPL.   DOT < EPL: rows_dot <= LPP DOT, rows_tot - rows_dot <=
+// LPP (EPL - DOT).
+// LPP = 16 keeps the latency of ONE solve low (few matrices, e.g. the k x k principal-angle problems).
+// LPP = 4 is the throughput shape for large batches of small matrices (the Procrustes cores, 1024 x (98 x 49) at
+// cfg-2): the rotation (~30 scalar-like instructions) is computed once per 4 lanes instead of once per 16 and the
+// cross-lane sum is 2 DPP steps instead of 4, so a matrix round costs about a third of the instruction issues --
+// the kernel is bound by VALU / LDS issue with every CU holding several matrices, not by the latency of a round.
 // ---------------------------------------------------------------------------
-template <int EPL, int DOT>
+template <int EPL, int DOT, int LPP = 16>
 __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W, long batch_stride, int rows_dot,
                                                            int rows_tot, int n_fixed, const int* __restrict__ n_arr,
                                                            int max_sweeps, float tol, float* __restrict__ colnorm,
                                                            int colnorm_stride, int* __restrict__ sweeps_out) {
-    constexpr int LD = 16 * EPL + 2;   // even: 8-byte aligned columns for the paired accesses
+    constexpr int LD = LPP * EPL + 2;   // even: 8-byte aligned columns for the paired accesses
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m = blockIdx.x;
     int n = n_arr ? n_arr[m] : n_fixed;
@@ -171,11 +183,11 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
     // global (leading dim rows_tot) -> padded LDS columns
     for (int idx = tid; idx < n * rt; idx += nthr) {
         const int c = idx / rt, r = idx - c * rt;
-        lds[c * LD + lds_row<EPL, DOT, 16>(r, rd)] = Wm[(long)c * rows_tot + r];
+        lds[c * LD + lds_row<EPL, DOT, LPP>(r, rd)] = Wm[(long)c * rows_tot + r];
     }
     __syncthreads();
 
-    const int groups = nthr / 16, grp = tid / 16, gl = tid % 16;
+    const int groups = nthr / LPP, grp = tid / LPP, gl = tid % LPP;
     float* n2 = lds + n_even * LD;      // cached squared column norms
     float* dev = n2 + n_even;           // accumulated normalisation defects
     __shared__ int s_norm2_bits;
@@ -187,7 +199,7 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
         int rotated = 0;
         float norm2_max = 0.f;
         for (int c = grp; c < n_even; c += groups) {          // refresh the cached norms from the data
-            const float v = column_norm2<DOT, 16>(lds + c * LD, gl);
+            const float v = column_norm2<DOT, LPP>(lds + c * LD, gl);
             if (gl == 0) n2[c] = v;
         }
         __syncthreads();
@@ -197,7 +209,7 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
                 rr_pair(n_even, r, t, p, q);
                 if (p >= n || q >= n) continue;  // padding column of an odd-order matrix
                 if (p > q) { const int tmp = p; p = q; q = tmp; }
-                rotated |= rotate_pair<EPL, DOT, 16>(lds + p * LD, lds + q * LD, gl, tol, null2, norm2_max, n2 + p, n2 + q,
+                rotated |= rotate_pair<EPL, DOT, LPP>(lds + p * LD, lds + q * LD, gl, tol, null2, norm2_max, n2 + p, n2 + q,
                                                  dev + p, dev + q);
             }
             __syncthreads();
@@ -216,7 +228,7 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
 
     // column norms over the dot rows + write back, both with the accumulated defect folded in
     for (int c = grp; c < n; c += groups) {
-        const float a = column_norm2<DOT, 16>(lds + c * LD, gl);
+        const float a = column_norm2<DOT, LPP>(lds + c * LD, gl);
         if (gl == 0) {
             const float nv = sqrtf(a);
             colnorm[(long)m * colnorm_stride + c] = fmaf(nv, dev[c], nv);
@@ -224,7 +236,7 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
     }
     for (int idx = tid; idx < n * rt; idx += nthr) {
         const int c = idx / rt, r = idx - c * rt;
-        const float v = lds[c * LD + lds_row<EPL, DOT, 16>(r, rd)];
+        const float v = lds[c * LD + lds_row<EPL, DOT, LPP>(r, rd)];
         Wm[(long)c * rows_tot + r] = fmaf(v, dev[c], v);
     }
 }
@@ -450,6 +462,38 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
     const int half = dot16 > ride16 ? dot16 : ride16;          // stacked layouts: EPL = 2 * DOT
     const int epl = stacked ? 2 * half : dot16;
     BASD_CHECK_ARG(!(stacked && n_arr));
+
+    // ---- LDS-resident, throughput shape: large batches of small stacked matrices, 4 lanes per column pair ----
+    if (stacked && batch >= 256 && n_even >= 8) {
+        const int dot8 = (rows_dot + 7) / 8, ride8 = (rows_tot - rows_dot + 7) / 8;
+        const int half8 = dot8 > ride8 ? dot8 : ride8;            // 8-row chunks per half; DOT = 2 * half8 elements / lane
+        static const int q_dot[] = {8, 12, 14, 16};
+        int d4 = 0;
+        for (int dq : q_dot)
+            if (dq >= 2 * half8) { d4 = dq; break; }
+        const size_t lds4 = (size_t)n_even * (4 * 2 * d4 + 4) * sizeof(float);
+        if (d4 && lds4 <= BASD_JACOBI_LDS_LIMIT) {
+            int threads = (((n_even / 2) * 4 + 63) / 64) * 64;
+            if (threads > 1024) threads = 1024;
+#define LAUNCH_LDS4(D)                                                                                               \
+    do {                                                                                                             \
+        if (lds4 > 48 * 1024)                                                                                        \
+            (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<2 * (D), D, 4>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BASD_JACOBI_LDS_LIMIT);            \
+        jacobi_lds_kernel<2 * (D), D, 4><<<batch, threads, lds4, stream>>>(W, batch_stride, rows_dot, rows_tot, n,   \
+                                                                           n_arr, max_sweeps, tol, colnorm,          \
+                                                                           colnorm_stride, sweeps_out);              \
+    } while (0)
+            switch (d4) {
+                case 8: LAUNCH_LDS4(8); break;
+                case 12: LAUNCH_LDS4(12); break;
+                case 14: LAUNCH_LDS4(14); break;
+                default: LAUNCH_LDS4(16); break;
+            }
+#undef LAUNCH_LDS4
+            BASD_RETURN_LAST();
+        }
+    }
 
     // ---- LDS-resident: the whole (padded) matrix in one CU ----
     static const int lds_epl[] = {2, 4, 6, 8, 12, 16, 20};

@@ -101,7 +101,8 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
                                                        int batch_pad, int P, float* __restrict__ d,
                                                        float* __restrict__ e, float* __restrict__ tau_out,
                                                        float* __restrict__ Vh, uint4* __restrict__ xg,
-                                                       int* __restrict__ err, unsigned tag_base, int lag_member) {
+                                                       int* __restrict__ err, unsigned tag_base, int lag_member,
+                                                       int j_stop, float* __restrict__ pend) {
     // ONE pass over the trailing block per step: the rank-2 update of step j-1 is applied lazily while the
     // rows are read for the matrix-vector product of step j (a' = a - v_r w_c - w_r v_c ; p_r += a' u_c), and
     // the column the next reflector is built from is captured on the way.  All vectors are indexed by ABSOLUTE
@@ -176,7 +177,10 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         for (int r = 2 + tid; r < n; r += nthr) part = fmaf(col[r], col[r], part);
         form_reflector(0, block_sum_lds(part, red, nw));
     }
-    for (int j = 0; j < n - 1; ++j) {
+    // j_stop < n - 1: only steps [0, j_stop) are done here; the trailing block of order n - j_stop goes on in
+    // tridiag_tail_kernel (registers of one CU, no exchange), which gets the matrix rows as stored by the last pass
+    // plus the still pending rank-2 update (v, w) of step j_stop - 1 through `pend`.
+    for (int j = 0; j < n - 1 && j < j_stop; ++j) {
         const int r0 = j + 1;
         if (r0 / TRI_BLK > my_last_blk) break;       // uniform over the workgroup
         if (p == lag_member) __builtin_amdgcn_s_sleep(127);      // test hook: one member falls behind every step
@@ -310,10 +314,21 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
             w[r] = wn;
         }
         const float xn2 = block_sum_lds(part, red, nw);   // its barrier also publishes col[] / v[] / w[]
-        if (j + 1 < n - 1) form_reflector(j + 1, xn2);
+        if (j + 1 < n - 1 && j + 1 < j_stop) form_reflector(j + 1, xn2);
     }
     __syncthreads();
     if (budget <= 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j_stop < n - 1) {
+        // hand-over: the owner of row j_stop was in step to the end, its (v, w) are those of step j_stop - 1
+        if (p == (j_stop / TRI_BLK) % P) {
+            float* pz = pend + (long)z * 2 * n;
+            for (int r = tid; r < n; r += nthr) {
+                pz[r] = v[r];
+                pz[n + r] = w[r];
+            }
+        }
+        return;
+    }
     if (p == last_owner) {
         if (tid == 0) {
             dz[n - 1] = col[n - 1];
@@ -322,6 +337,184 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         }
         for (int c = tid; c < n; c += nthr) Vz[(long)(n - 1) * n + c] = 0.f;
     }
+}
+
+// ---------------------------------------------------------------------------
+// The same factorisation for a trailing block that fits ONE CU's registers: steps [j0, n-1) on the block of order
+// m = n - j0 <= 64 * CPL, one workgroup of 64 * WAVES threads per matrix, no exchange with anybody.
+// Thread (wave w, lane l) keeps M[w + WAVES * i][l + 64 * k] (i < RPW, k < CPL) in registers for the whole
+// factorisation; a step is one pass over the registers (pending rank-2 update of the previous step applied lazily,
+// product with the current reflector accumulated on the way) and four workgroup barriers:
+//   pass      a' = a - v_r w_c - w_r v_c ;  acc_c += a' u_r           (u_r, v_r, w_r wave-uniform: LDS broadcasts)
+//   A         per-wave column partials -> LDS;  threads c < m: p_c = tau * sum over waves
+//   B         gamma = -tau/2 p.u ;  w = p + gamma u ;  next pivot row (captured by the pass) updated analytically
+//   C         its norm -> reflector of the next step (d, e, tau written)
+//   D         u, v, w published;  reflector row stored to Vh
+// It is the algorithm of tridiag_kernel run on the transpose (rows take the part of columns: the matrix is
+// symmetric), with the row-wise sums replaced by per-lane column sums so that no cross-lane reduction sits in the
+// pass.  Rows that are already reduced are skipped (wave-uniform), so the pass shrinks with the trailing block.
+// n <= 64 * CPL: the whole factorisation (j0 = 0, pend = nullptr) -- nothing spins anywhere.
+// n >  64 * CPL: tridiag_kernel does steps [0, j0) and hands over the pending update (pend: v, w of step j0 - 1).
+// ---------------------------------------------------------------------------
+template <int WAVES, int RPW, int CPL>
+__global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restrict__ A, long a_batch_stride, int n,
+                                                                  int j0, const float* __restrict__ pend,
+                                                                  float* __restrict__ d, float* __restrict__ e,
+                                                                  float* __restrict__ tau_out,
+                                                                  float* __restrict__ Vh) {
+    constexpr int MMAX = 64 * CPL;
+    static_assert(WAVES * RPW >= MMAX, "every row needs an owner");
+    static_assert(WAVES * 64 >= MMAX, "one thread per column in the vector phases");
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ float u[MMAX], v[MMAX], w[MMAX], cap[MMAX], pw[MMAX], col[MMAX];
+    __shared__ float part[WAVES][MMAX];
+    __shared__ float red[2][16];
+    const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = n - j0;
+    float* Az = A + (long)z * a_batch_stride;
+    float* dz = d + (long)z * n;
+    float* ez = e + (long)z * n;
+    float* tz = tau_out + (long)z * n;
+    float* Vz = Vh + (long)z * n * n;
+    const float* pz = pend ? pend + (long)z * 2 * n : nullptr;
+
+    // ---- load the trailing block (pending update applied), zero padded to MMAX
+    float a[RPW][CPL];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave + WAVES * i;
+        const float vr = (pz && r < m) ? pz[j0 + r] : 0.f, wr = (pz && r < m) ? pz[n + j0 + r] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int c = lane + 64 * k;
+            float x = 0.f;
+            if (r < m && c < m) {
+                x = Az[(long)(j0 + r) * n + j0 + c];
+                if (pz) x -= fmaf(vr, pz[n + j0 + c], wr * pz[j0 + c]);
+            }
+            a[i][k] = x;
+        }
+    }
+    for (int c = tid; c < MMAX; c += 64 * WAVES) {
+        u[c] = 0.f;
+        v[c] = 0.f;
+        w[c] = 0.f;
+        cap[c] = 0.f;
+    }
+    // row 0 of the block: what the first reflector is built from
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) col[lane + 64 * k] = a[0][k];
+    }
+    __syncthreads();
+
+    // reflector of local step jl from col[] (row jl of the current block, entries >= jl), as tridiag_kernel's
+    // form_reflector; threads c < MMAX write u; d / e / tau by one thread.  xn2 = sum_{c > jl + 1} col[c]^2.
+    float tau = 0.f;
+    auto form_reflector = [&](int jl, float xn2) {
+        const int r0 = jl + 1;
+        const float alpha = col[r0];
+        float beta = alpha;
+        tau = 0.f;
+        if (xn2 > 0.f) {
+            beta = -copysignf(sqrtf(fmaf(alpha, alpha, xn2)), alpha);
+            tau = (beta - alpha) / beta;
+        }
+        if (tid == 0) {
+            dz[j0 + jl] = col[jl];
+            ez[j0 + jl] = beta;
+            tz[j0 + jl] = tau;
+        }
+        const float scal = tau != 0.f ? 1.f / (alpha - beta) : 0.f;
+        if (tid < MMAX) u[tid] = tid < r0 ? 0.f : (tid == r0 ? 1.f : col[tid] * scal);
+    };
+    auto block_sum4 = [&](float x, float* slot) {      // sum over the threads < MMAX (whole waves), one barrier
+        x = wave_sum(x);
+        if (lane == 0 && tid < MMAX) slot[wave] = x;
+        __syncthreads();
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) r += slot[i];
+        return r;
+    };
+    {
+        const float cv = tid < MMAX ? col[tid] : 0.f;
+        const float xn2 = block_sum4((tid > 1 && tid < MMAX) ? cv * cv : 0.f, red[0]);
+        form_reflector(0, xn2);
+        __syncthreads();
+    }
+    // the reflector row of step j in Vh: zeros up to column j, then u
+    auto store_reflector = [&](int jl) {
+        float* vrow = Vz + (long)(j0 + jl) * n;
+        for (int c = tid; c < n; c += 64 * WAVES) vrow[c] = c < j0 ? 0.f : u[c - j0];
+    };
+    store_reflector(0);
+
+    for (int jl = 0; jl < m - 1; ++jl) {
+        const int r0 = jl + 1;
+        // ---- pass over the registers
+        float vc[CPL], wc[CPL], acc[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            vc[k] = v[lane + 64 * k];
+            wc[k] = w[lane + 64 * k];
+            acc[k] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave + WAVES * i;
+            if (r >= r0 && r < m) {                      // wave-uniform
+                const float ur = u[r], vr = v[r], wr = w[r];
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    a[i][k] -= fmaf(vr, wc[k], wr * vc[k]);
+                    acc[k] = fmaf(a[i][k], ur, acc[k]);
+                }
+                if (r == r0) {                           // the row the next reflector is built from
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) cap[lane + 64 * k] = a[i][k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) part[wave][lane + 64 * k] = acc[k];
+        __syncthreads();                                                                   // A
+        float pc = 0.f, uc = 0.f;
+        if (tid < MMAX) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int q = 0; q < WAVES; ++q) sacc += part[q][tid];
+            pc = tau * sacc;
+            uc = u[tid];
+            pw[tid] = pc;
+        }
+        const float gamma = -0.5f * tau * block_sum4(tid < MMAX ? pc * uc : 0.f, red[1]);   // B (publishes pw)
+        float wn = 0.f, part2 = 0.f;
+        if (tid < MMAX) {
+            const float w0 = pw[r0] + gamma;             // u[r0] = 1
+            if (tid >= r0) {
+                wn = fmaf(gamma, uc, pc);
+                const float cn = cap[tid] - fmaf(uc, w0, wn);
+                col[tid] = cn;
+                if (tid > r0 + 1) part2 = cn * cn;
+            }
+        }
+        const float xn2 = block_sum4(part2, red[0]);                                        // C (publishes col)
+        if (tid < MMAX) {
+            v[tid] = uc;
+            w[tid] = wn;
+        }
+        if (jl + 1 < m - 1) form_reflector(jl + 1, xn2);
+        __syncthreads();                                                                    // D
+        if (jl + 1 < m - 1) store_reflector(jl + 1);
+    }
+    if (tid == 0) {
+        dz[n - 1] = col[m - 1];
+        ez[n - 1] = 0.f;
+        tz[n - 1] = 0.f;
+    }
+    for (int c = tid; c < n; c += 64 * WAVES) Vz[(long)(n - 1) * n + c] = 0.f;
 }
 
 // ---------------------------------------------------------------------------
@@ -843,24 +1036,61 @@ extern "C" {
 
 // Householder tridiagonalisation of `batch` symmetric matrices (destroyed).  d, e, tau: (batch, n);
 // vh: (batch, n, n) reflector rows.
-// Members per matrix: up to one 32-row block per member (measured on MI355X at n = 384, 6 matrices: 3.12 ms with
-// 1 member, 1.95 with 4, 1.63 with 12), while every workgroup of the launch is certainly resident (the members spin on each other): at most
-// 128 workgroups per launch, so that two concurrent factorisations still fit the 256 CUs.
+//
+// Two stages.  The trailing block of order <= 256 is factored by tridiag_tail_kernel in the registers of ONE CU per
+// matrix (no exchange, nothing spins: n <= 256 never leaves that kernel).  For n > 256 the first n - 256 steps --
+// where one CU's issue rate and L2 bandwidth bound a step -- run on tridiag_kernel with the matrix shared by up to 16
+// workgroups ("members", one 32-row block each at n = 384; measured at n = 384, 6 matrices, whole factorisation:
+// 3.12 ms with 1 member, 1.95 with 4, 1.63 with 12).  Members poll each other's granules, so all of them must be
+// resident: at most 128 workgroups per launch (two concurrent launches still fit the 256 CUs).
 static int nblk_of(int n) { return (n + TRI_BLK - 1) / TRI_BLK; }
 
+constexpr int TRI_TAIL_MAX = 256;      // order of the register-resident trailing block (64 * CPL of the tail kernel)
+
+// Tuning / test hooks, read ONCE when the library is loaded (never inside an entry point):
+//   BASD_TRIDIAG_MEMBERS  members per matrix in the shared stage (default: one per 32-row block, <= 16)
+//   BASD_TRIDIAG_PAD      workgroup-id padding between matrices (scatters the members over XCDs; tests)
+//   BASD_TRIDIAG_LAG      member that sleeps every step (tests the hand-off under uneven progress)
+//   BASD_TRIDIAG_THREADS  threads per member
+//   BASD_TRIDIAG_TAIL     0: whole factorisation in the shared stage (the round-1 path; tests compare the two)
+struct TridiagTuning {
+    int members = 0, pad = -1, lag = -1, threads = 0, tail = 1;
+    TridiagTuning() {
+        if (const char* s = getenv("BASD_TRIDIAG_MEMBERS")) members = atoi(s);
+        if (const char* s = getenv("BASD_TRIDIAG_PAD")) pad = atoi(s);
+        if (const char* s = getenv("BASD_TRIDIAG_LAG")) lag = atoi(s);
+        if (const char* s = getenv("BASD_TRIDIAG_THREADS")) threads = atoi(s);
+        if (const char* s = getenv("BASD_TRIDIAG_TAIL")) tail = atoi(s);
+    }
+};
+static TridiagTuning g_tuning;
+
 static int tridiag_members(int n, int batch) {
-    const int nblk = (n + TRI_BLK - 1) / TRI_BLK;
-    int p = nblk;
-    if (const char* s = getenv("BASD_TRIDIAG_MEMBERS")) p = atoi(s);
+    const int nblk = nblk_of(n);
+    int p = g_tuning.members > 0 ? g_tuning.members : nblk;
     if (p > 16) p = 16;
     while (p > 1 && p * batch > 128) --p;
     if (p > nblk) p = nblk;
     return p < 1 ? 1 : p;
 }
 
+// Test / tuning hook: overrides the values read from the environment at load time (negative = keep the current value;
+// `reset` != 0 first restores the load-time environment values).  Process-wide; meant for tests and experiments, not for
+// use while factorisations are being queued from other threads.
+int basd_tridiag_tuning(int members, int pad, int lag, int threads, int tail, int reset) {
+    if (reset) g_tuning = TridiagTuning();
+    if (members >= 0) g_tuning.members = members;
+    if (pad >= 0) g_tuning.pad = pad;
+    if (lag >= 0) g_tuning.lag = lag;
+    if (threads >= 0) g_tuning.threads = threads;
+    if (tail >= 0) g_tuning.tail = tail;
+    return BASD_OK;
+}
+
 long basd_tridiag_workspace_bytes(int n, int batch) {
-    // per matrix: 2 parities x n granules of 16 bytes; plus the status word and 7 words of give-up trace
-    return (long)batch * 2 * n * 16 + 32;
+    // per matrix: 2 parities x n granules of 16 bytes, then the pending (v, w) handed to the tail stage; at the very
+    // end the status word and 7 words of give-up trace
+    return (long)batch * 2 * n * 16 + (long)batch * 2 * n * 4 + 32;
 }
 
 int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
@@ -868,26 +1098,37 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
     BASD_CHECK_ARG(a && d && e && tau && vh && work && n > 1 && batch > 0);
     BASD_CHECK_ARG((((uintptr_t)work) & 15) == 0);
     if (n > 4096) return BASD_EUNSUPPORTED;
-    const bool vec = (n & 3) == 0 && (a_batch_stride & 3) == 0 && (((uintptr_t)a) & 15) == 0;
-    const int P = tridiag_members(n, batch);
-    int batch_pad = P > 1 ? (batch + 7) & ~7 : batch;
-    if (const char* s = getenv("BASD_TRIDIAG_PAD")) batch_pad = batch + atoi(s);     // experiment: scatter members over XCDs
     const long gran_bytes = (long)batch * 2 * n * 16;
     uint4* xg = (uint4*)work;
-    int* err = (int*)((char*)work + gran_bytes);
-    // 20-bit launch nonce in the granule tags (12 bits of step below it: n <= 4096)
-    static std::atomic<unsigned> launches{0};
-    const unsigned tag_base = ((launches.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xFFFFFu) << 12;
-    const size_t lds = sizeof(float) * 9 * (size_t)n;
-    int lag = -1;                                   // BASD_TRIDIAG_LAG=<member>: test hook, see tridiag_kernel
-    if (const char* s = getenv("BASD_TRIDIAG_LAG")) lag = atoi(s);
-    // a member with one 32-row block keeps only four waves busy in the pass: fewer waves make the barriers
-    // cheaper (n = 384, 12 members: 1.63 ms with 1024 threads, 1.55 with 512, 1.66 with 256)
-    int threads = (P > 1 && (nblk_of(n) + P - 1) / P <= 1) ? 512 : 1024;
-    if (const char* s = getenv("BASD_TRIDIAG_THREADS")) threads = atoi(s);
-    if (vec && (n & 7) == 0) tridiag_kernel<true, true><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag);
-    else if (vec) tridiag_kernel<true, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag);
-    else tridiag_kernel<false, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag);
+    float* pend = (float*)((char*)work + gran_bytes);
+    int* err = (int*)((char*)work + gran_bytes + (long)batch * 2 * n * 4);
+    const bool tail = g_tuning.tail != 0;
+    const int j_stop = !tail ? n - 1 : (n > TRI_TAIL_MAX ? n - TRI_TAIL_MAX : 0);
+    if (j_stop > 0) {
+        const bool vec = (n & 3) == 0 && (a_batch_stride & 3) == 0 && (((uintptr_t)a) & 15) == 0;
+        const int P = tridiag_members(n, batch);
+        int batch_pad = P > 1 ? (batch + 7) & ~7 : batch;
+        if (g_tuning.pad >= 0) batch_pad = batch + g_tuning.pad;
+        // 20-bit launch nonce in the granule tags (12 bits of step below it: n <= 4096), never 0: a zero-filled
+        // granule of fresh memory must not look like step 0 of any launch.  The counter only has to differ between
+        // launches that can see each other's granules (same recycled buffer), not to be unique for ever.
+        static std::atomic<unsigned> launches{0};
+        const unsigned tag_base = (1u + launches.fetch_add(1, std::memory_order_relaxed) % 0xFFFFFu) << 12;
+        const size_t lds = sizeof(float) * 9 * (size_t)n;
+        // a member with one 32-row block keeps only four waves busy in the pass: fewer waves make the barriers
+        // cheaper (n = 384, 12 members: 1.63 ms with 1024 threads, 1.55 with 512, 1.66 with 256)
+        int threads = (P > 1 && (nblk_of(n) + P - 1) / P <= 1) ? 512 : 1024;
+        if (g_tuning.threads > 0) threads = g_tuning.threads;
+        const int lag = g_tuning.lag;
+        if (vec && (n & 7) == 0) tridiag_kernel<true, true><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag, j_stop, pend);
+        else if (vec) tridiag_kernel<true, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag, j_stop, pend);
+        else tridiag_kernel<false, false><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag, j_stop, pend);
+    } else {
+        hipError_t me = hipMemsetAsync(err, 0, 32, stream);        // no shared stage: the status words stay clean
+        if (me != hipSuccess) return (int)me;
+    }
+    if (tail)
+        tridiag_tail_kernel<16, 16, 4><<<batch, 1024, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh);
     BASD_RETURN_LAST();
 }
 
