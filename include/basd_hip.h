@@ -102,6 +102,10 @@ int basd_jacobi_workspace_ints(int batch, int max_sweeps);
  * (:36, :92), torch.linalg.svdvals (:99) and torch.linalg.matrix_norm(ord="nuc") (relational.py:48).
  * n_arr (nullable): per-matrix order for square problems.  flags: basd_jacobi_workspace_ints() ints.
  * tol_cos: stop when every pair has |cos| <= tol_cos over a full sweep (<= 0: eps * sqrt(rows_dot)). */
+/* Test / tuning hook: lanes per column pair of the LDS-resident solver; 0 or 16 = one DPP row of 16 lanes (default),
+ * 4 = one quad (stacked matrices only; same results, measured no faster). */
+int basd_jacobi_tuning(int lanes_per_pair);
+
 int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot, int n, int batch,
                          const int* n_arr, float* colnorm, int colnorm_stride, int max_sweeps, float tol_cos,
                          int* flags, int* sweeps_out, hipStream_t stream);
@@ -127,6 +131,14 @@ long basd_tridiag_workspace_bytes(int n, int batch);
  * partners, and a trace of the first give-up (step + 1, row, member | matrix << 8, tag seen, tag wanted). */
 int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
                  void* work, hipStream_t stream);
+
+/* basd_tridiag + the Marchenko-Pastur ranks (see basd_tridiag_mp_rank; layer_selector.py:16-19, :74) of the FIRST
+ * rank_count matrices of the batch, computed by the workgroup that finishes each factorisation -- no separate launch on
+ * the path the host waits for.  host_mirror (nullable): pinned host memory of rank_count + 8 ints that receives the
+ * ranks and then the factorisation's 8 status words. */
+int basd_tridiag_ranked(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
+                        void* work, int rank_count, double factor, int cap, int* rank_out, int* host_mirror,
+                        hipStream_t stream);
 
 /* Test / tuning hook for basd_tridiag (the only process-wide setting of the library; its defaults come from the
  * BASD_TRIDIAG_{MEMBERS,PAD,LAG,THREADS,TAIL} environment variables, read ONCE when the library is loaded -- no
@@ -226,13 +238,15 @@ int basd_gram_f64(const float* p, long p_batch_stride, int n, int D, int batch, 
 int basd_chol_f64(const double* g, long g_batch_stride, int n, int batch, double* l, long l_batch_stride,
                   hipStream_t stream);
 
-/* W[b] = [L_a^T L_b ; L_b]  (2n x n column-major fp32) -- the input of basd_jacobi_onesided. */
-int basd_stack_product(const double* la, const double* lb, long l_batch_stride, int n, int batch, float* w,
-                       long w_batch_stride, hipStream_t stream);
+/* W[b] = [L_a^T L_b[b % lb_period] ; L_b[b % lb_period]]  (2n x n column-major fp32) -- the input of
+ * basd_jacobi_onesided.  lb_period < batch: one teacher factor per sample shared by all extraction layers. */
+int basd_stack_product(const double* la, const double* lb, long l_batch_stride, int n, int batch, int lb_period,
+                       float* w, long w_batch_stride, hipStream_t stream);
 
 /* Per sample: tr_t, nuclear norm (relational.py:48), loss_b = tr_s + tr_t - 2 nuc (relational.py:50),
  * and K' = Y Sigma^+ Y^T for the backward (nullable). */
 int basd_procrustes_finalize(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
+                             int t_period /* gb, omega indexed by b % t_period */,
                              const double* gb, long g_batch_stride, const float* omega, const int* tap0,
                              const int* tap1, const float* lam, const float* tr_s_part, int tr_slabs, float* tr_s,
                              float* tr_t, float* nuc, float* loss, float* k_prime, hipStream_t stream);
@@ -243,6 +257,62 @@ int basd_student_grad(const void* x, int dtype, long sb, long sn, int B, int n_s
                       const float* mu, const float* h, const int* tap0, const int* tap1, const float* lam,
                       const float* scale_ptr, float scale_const, float* dx, const float* tnorm2, float* gomega,
                       hipStream_t stream);
+
+/* basd_student_project / basd_student_grad for all E extraction layers in ONE launch each.  x_ptrs: device table of
+ * E base pointers (common strides); omega + e * omega_e_stride (0 = one weight vector for all layers); the other
+ * operands are laid out (E, B, ...); scale_ptr[e] = upstream gradient of layer e.
+ * basd_student_project_multi returns BASD_EUNSUPPORTED where its vectorised LDS-staged kernel does not apply (rows not
+ * 16-byte aligned, slab over 64 KB): fall back to basd_student_project per layer. */
+int basd_student_project_multi(const void* const* x_ptrs, int dtype, long sb, long sn, int E, int B, int n_s, int n_t,
+                               int D, int ptrs_16B_aligned, const float* omega, long omega_e_stride, const int* tap0,
+                               const int* tap1, const float* lam, const int* range0, const int* range1, float* mu,
+                               float* tr_s, float* a_prime, hipStream_t stream);
+int basd_student_grad_multi(const void* const* x_ptrs, int dtype, long sb, long sn, int E, int B, int n_s, int n_t,
+                            int D, const float* omega, long omega_e_stride, const float* mu, const float* h,
+                            const int* tap0, const int* tap1, const float* lam, const float* scale_ptr,
+                            float scale_const, float* dx, const float* tnorm2, float* gomega, hipStream_t stream);
+
+/* The whole forward of relational.py:22-50 for E extraction layers against the (mixed) teacher -- and, when `dx` is
+ * set, the student-token gradients for the upstream gradients `grad_layers` -- queued by ONE call: the launches of
+ * basd_token_weights, basd_teacher_center, basd_student_project(_multi), basd_gram_f64 x2, basd_chol_f64,
+ * basd_stack_product, basd_jacobi_onesided, basd_procrustes_finalize [, basd_gemm_tn, basd_student_grad_multi] in
+ * that order (a dozen FFI calls from Python cost several times the launches themselves, and that host time sat in
+ * front of the caller's stream).  All fields are 8 bytes wide; pointers are device memory except student_host_ptrs.
+ *   G = 1: the teacher side is shared by all layers (one teacher layer: mixing weights exactly 1), else G = E.
+ *   n = min(n_s, n_t): the core grid.  Arrays: omega (G,B,n_s), omega_t (G,B,n), raw (G,B,n_a) nullable,
+ *   mu_t (G,B,d_t), tc (G,B,n,d_t), mu_s (E,B,d_s), tr_part (E,B,ceil(d_s/64)), tr_s/tr_t/nuc/loss_b (E,B),
+ *   a_prime (E,B,n,d_s), g_all/l_all ((E+G)B,n,n) fp64, W (EB,n,2n), sigma (EB,n),
+ *   jflags basd_jacobi_workspace_ints(EB, max_sweeps) ints, sweeps (EB) ints nullable, k_prime (EB,n,n) nullable,
+ *   h (EB,n,d_s) + dx (E,B,n_s,d_s) + grad_layers (E): only for the gradients. */
+typedef struct BasdProcrustesArgs {
+    const void* const* student_ptrs;       /* device table of E pointers */
+    const void* const* student_host_ptrs;  /* the same E pointers in host memory (per-layer fallback) */
+    long s_dtype, s_sb, s_sn, s_aligned;
+    const void* const* tok_ptrs;           /* device table of L pointers */
+    long t_dtype, t_sb, t_sn, t_sd;
+    const void* const* attn_ptrs;          /* device table of L pointers */
+    long a_dtype, a_sb, a_sh, a_sq, a_sk;
+    const float* mix;                      /* (G, L) */
+    long E, L, G, B, n_s, n_t, d_s, d_t, H, A, has_cls, n_a, n, max_sweeps;
+    const int* atap0; const int* atap1; const float* alam;                                  /* n_a -> n_s */
+    const int* tap0; const int* tap1; const float* lam; const int* range0; const int* range1;   /* n -> n_s, student side */
+    const int* g0; const int* g1; const float* glam;                                        /* teacher gather n_t -> n */
+    float* omega; float* omega_t; float* raw; float* mu_t; float* tc; float* mu_s; float* tr_part; float* tr_s;
+    float* a_prime;
+    double* g_all; double* l_all;
+    float* W; float* sigma; int* jflags; int* sweeps;
+    float* tr_t; float* nuc; float* loss_b; float* k_prime;
+    float* h; float* dx; const float* grad_layers;
+} BasdProcrustesArgs;
+int basd_procrustes_forward_fused(const BasdProcrustesArgs* args, hipStream_t stream);
+
+/* ---- CU partitions (hipExtStreamCreateWithCUMask) --------------------------------------------------- */
+
+/* A stream confined to CUs [cu_lo, cu_hi) of EVERY XCD (invert = 0) or to all the others (invert != 0); 32 CUs per XCD
+ * on MI355X.  The selector's eigen-solve chains (dependent, latency-bound launches of a few workgroups) are queued on
+ * such partitions and this library's throughput kernels on the complement, so that neither slows the other down. */
+int basd_stream_create_masked(int cu_lo, int cu_hi, int invert, hipStream_t* out);
+int basd_stream_destroy(hipStream_t stream);
 
 /* ---- multi-layer teachers only: gradients through the mixing weights and the principal angles ------ */
 

@@ -27,11 +27,13 @@ SIGNATURES = {
     "basd_syrk_splits": [i32, i32, i32],
     "basd_syrk_multi": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, i32, vp, vp, i64, i32, vp, i32, i32, vp],
     "basd_jacobi_workspace_ints": [i32, i32],
+    "basd_jacobi_tuning": [i32],
     "basd_jacobi_onesided": [vp, i64, i32, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp],
     "basd_sort_extract": [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
     "basd_tridiag_workspace_bytes": [i32, i32],
     "basd_tridiag_tuning": [i32, i32, i32, i32, i32, i32],
     "basd_tridiag": [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp],
+    "basd_tridiag_ranked": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp],
     "basd_tridiag_eigenvalues": [vp, vp, i32, i32, vp, vp],
     "basd_tridiag_apply_q": [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp],
     "basd_tridiag_shifted_solve": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
@@ -47,9 +49,16 @@ SIGNATURES = {
     "basd_teacher_center": [vp, i32, vp, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_gram_f64": [vp, i64, i32, i32, i32, vp, i64, vp],
     "basd_chol_f64": [vp, i64, i32, i32, vp, i64, vp],
-    "basd_stack_product": [vp, vp, i64, i32, i32, vp, i64, vp],
-    "basd_procrustes_finalize": [vp, i64, vp, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp,
-                                 vp],
+    "basd_stack_product": [vp, vp, i64, i32, i32, i32, vp, i64, vp],
+    "basd_procrustes_finalize": [vp, i64, vp, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp,
+                                 vp, vp],
+    "basd_student_project_multi": [vp, i32, i64, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp,
+                                   vp, vp, vp],
+    "basd_student_grad_multi": [vp, i32, i64, i64, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp,
+                                vp, vp, vp],
+    "basd_procrustes_forward_fused": [vp, vp],
+    "basd_stream_create_masked": [i32, i32, i32, vp],
+    "basd_stream_destroy": [vp],
     "basd_resample_tokens": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "basd_resample_tokens_adjoint": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_student_grad": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp],
@@ -61,6 +70,24 @@ SIGNATURES = {
     "basd_grassmann_distance_bwd": [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp],
     "basd_eigvec_k2": [vp, vp, i32, i32, i32, vp, vp],
 }
+
+class ProcrustesArgs(C.Structure):
+    """BasdProcrustesArgs of include/basd_hip.h (every field 8 bytes wide)."""
+    _PTRS = ("student_ptrs", "student_host_ptrs")
+    _fields_ = (
+        [("student_ptrs", vp), ("student_host_ptrs", vp)]
+        + [(n, i64) for n in ("s_dtype", "s_sb", "s_sn", "s_aligned")]
+        + [("tok_ptrs", vp)] + [(n, i64) for n in ("t_dtype", "t_sb", "t_sn", "t_sd")]
+        + [("attn_ptrs", vp)] + [(n, i64) for n in ("a_dtype", "a_sb", "a_sh", "a_sq", "a_sk")]
+        + [("mix", vp)]
+        + [(n, i64) for n in ("E", "L", "G", "B", "n_s", "n_t", "d_s", "d_t", "H", "A", "has_cls", "n_a", "n",
+                              "max_sweeps")]
+        + [(n, vp) for n in ("atap0", "atap1", "alam", "tap0", "tap1", "lam", "range0", "range1", "g0", "g1", "glam",
+                             "omega", "omega_t", "raw", "mu_t", "tc", "mu_s", "tr_part", "tr_s", "a_prime", "g_all",
+                             "l_all", "W", "sigma", "jflags", "sweeps", "tr_t", "nuc", "loss_b", "k_prime", "h", "dx",
+                             "grad_layers")]
+    )
+
 
 # sizing helpers declared `long` in include/basd_hip.h
 LONG_RESULTS = {"basd_tridiag_workspace_bytes"}

@@ -51,6 +51,10 @@ def _ptr(t: torch.Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
 
+# Stream that will read the outputs of an autograd node running on a CU-partition stream (BASDLoss.forward sets it
+# around the node's forward; the node's backward marks its results as in use there).
+CONSUMER_STREAM = None
+
 # Host-side timeline of a step (tools/host_timeline.py): list of (label, perf_counter) when switched on.
 HOST_TRACE: list | None = None
 
@@ -239,11 +243,16 @@ class TridiagState:
     vals: torch.Tensor      # (batch, n) descending
     err: torch.Tensor | None = None   # (8,) int32; [0] non-zero if the workgroups sharing a matrix lost each other
                                       # ([1:6] then: step + 1, row, member | matrix << 8, tag seen, tag wanted)
+    ranks: torch.Tensor | None = None   # Marchenko-Pastur ranks of the leading matrices (``tridiagonalise(mp_rank=)``)
 
 
-def tridiagonalise(G: torch.Tensor) -> TridiagState:
+def tridiagonalise(G: torch.Tensor, mp_rank: tuple | None = None) -> TridiagState:
     """G (batch, n, n) symmetric, DESTROYED.  Queues the Householder tridiagonalisation; ``vals`` is allocated but
-    not filled (``tridiag_spectrum``).  No host sync."""
+    not filled (``tridiag_spectrum``).  No host sync.
+    ``mp_rank`` = (M, D, cap, count, host_mirror | None): also the Marchenko-Pastur ranks of the first ``count``
+    matrices (``ts.ranks``, int32 on device), from the kernel that finishes the factorisation; ``host_mirror``: pinned
+    int32 host tensor of count + 8 elements filled with the ranks and the status words (read it after an event
+    recorded behind this call)."""
     _require_cuda(G)
     assert G.dtype == torch.float32 and G.is_contiguous() and G.dim() == 3 and G.shape[1] == G.shape[2]
     batch, n, _ = G.shape
@@ -252,9 +261,19 @@ def tridiagonalise(G: torch.Tensor) -> TridiagState:
     vh = torch.empty((batch, n, n), **f32)
     vals = torch.empty((batch, n), **f32)
     work = torch.empty((_lib.query("basd_tridiag_workspace_bytes", n, batch),), device=G.device, dtype=torch.uint8)
-    _lib.call("basd_tridiag", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
-              vh.data_ptr(), work.data_ptr(), _stream())
-    return TridiagState(d, e, tau, vh, vals, work[-32:].view(torch.int32))
+    ranks = None
+    if mp_rank is None:
+        _lib.call("basd_tridiag", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
+                  vh.data_ptr(), work.data_ptr(), _stream())
+    else:
+        M, D, cap, count, mirror = mp_rank
+        factor = (1 + (D / M) ** 0.5) ** 2          # float64 on the host, as reference layer_selector.py:11,18
+        ranks = torch.empty((count,), device=G.device, dtype=torch.int32)
+        if mirror is not None:
+            assert mirror.is_pinned() and mirror.dtype == torch.int32 and mirror.numel() == count + 8
+        _lib.call("basd_tridiag_ranked", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
+                  vh.data_ptr(), work.data_ptr(), count, factor, cap, ranks.data_ptr(), _ptr(mirror), _stream())
+    return TridiagState(d, e, tau, vh, vals, work[-32:].view(torch.int32), ranks)
 
 
 def tridiag_spectrum(ts: TridiagState, first: int = 0, count: int | None = None) -> torch.Tensor:
@@ -340,6 +359,7 @@ def selector_tail(t_ts: TridiagState, t_first: int, L: int, s_ts: TridiagState, 
                        dtype=torch.int32)
     sw_index = _device_consts(tuple(range(L)) * E, torch.int32, dev)
     sl = slice(t_first, t_first + L)
+    trace("tail_alloc")
     _lib.call("basd_selector_tail", t_ts.d[sl].data_ptr(), t_ts.e[sl].data_ptr(), t_ts.tau[sl].data_ptr(),
               t_ts.vh[sl].data_ptr(), t_ts.vals[sl].data_ptr(), s_ts.d.data_ptr(), s_ts.e.data_ptr(),
               s_ts.tau.data_ptr(), s_ts.vh.data_ptr(), s_ts.vals.data_ptr(), n, E, L, kmax, ranks_dev.data_ptr(),
@@ -464,6 +484,7 @@ class ProcrustesContext:
     loss_b: torch.Tensor     # (E, B)
     sweeps: torch.Tensor | None
     mixgrad: dict | None = None   # extra state kept only when the mixing weights need a gradient
+    dx: torch.Tensor | None = None   # (E, B, n_s, D_s) student gradients queued with the forward (``grad_layers``)
 
 
 def _check_common_layout(tensors: list[torch.Tensor], what: str) -> list[torch.Tensor]:
@@ -482,12 +503,17 @@ def _check_common_layout(tensors: list[torch.Tensor], what: str) -> list[torch.T
 
 def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor], attns: list[torch.Tensor],
                        mix: torch.Tensor, has_cls: bool, *, need_backward: bool = True,
-                       want_sweeps: bool = False, need_mix_grad: bool = False) -> ProcrustesContext:
+                       want_sweeps: bool = False, need_mix_grad: bool = False,
+                       grad_layers: torch.Tensor | None = None) -> ProcrustesContext:
     """students: E tensors (B, N_s, D_s); teachers: L tensors (B, N_t, D_t); attns: L tensors (B, H, A, A);
-    mix: (E, L) fp32 mixing weights on device.  Returns per-sample terms for every extraction layer."""
+    mix: (E, L) fp32 mixing weights on device.  Returns per-sample terms for every extraction layer.
+    ``grad_layers`` ((E,) fp32 on device): also queue the student-token gradients for these upstream gradients
+    (``ctx.dx``: (E, B, N_s, D_s) fp32).  Everything is queued by ONE library call (basd_procrustes_forward_fused)."""
+    import ctypes
     E, L = len(students), len(teachers)
     students = [as_supported(s) for s in students]
-    students = [s if s.stride(2) == 1 else s.contiguous() for s in students]
+    students = _check_common_layout([s if s.stride(2) == 1 else s.contiguous() for s in students],
+                                    "student token tensors")
     teachers = _check_common_layout([as_supported(t) for t in teachers], "teacher token tensors")
     attns = _check_common_layout([as_supported(a) for a in attns], "teacher attention tensors")
     _require_cuda(*students, *teachers, *attns, mix)
@@ -502,71 +528,78 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     n = min(n_s, n_t)
     tp = taps(n_t, n_s, dev) if n_t < n_s else None                      # student-side (transposed) taps
     gt = taps(n_t, n_s, dev) if n_t > n_s else None                      # teacher-side gather taps
-    t0, t1, lam = (tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr()) if tp else (None, None, None)
-    r0, r1 = (tp.range0.data_ptr(), tp.range1.data_ptr()) if tp else (None, None)
-    g0, g1, glam = (gt.tap0.data_ptr(), gt.tap1.data_ptr(), gt.lam.data_ptr()) if gt else (None, None, None)
     atp = taps(n_a, n_s, dev)
-    a0, a1, alam = (atp.tap0.data_ptr(), atp.tap1.data_ptr(), atp.lam.data_ptr()) if atp else (None, None, None)
-    st = _stream()
     mix = mix.contiguous().float()
     shared = L == 1            # softmax over one layer is exactly 1: the teacher side is identical for all e
     G = 1 if shared else E
-    tok_tab, att_tab = _ptr_table(teachers), _ptr_table(attns)
     f32 = dict(device=dev, dtype=torch.float32)
-    omega = torch.empty((G, B, n_s), **f32)
-    omega_t = torch.empty((G, B, n), **f32)
-    mu_t = torch.empty((G, B, d_t), **f32)
-    tc = torch.empty((G, B, n, d_t), **f32)
-    sb, sh, sq, sk = attns[0].stride()
-    tsb, tsn, tsd = teachers[0].stride()
-    raw = torch.empty((G, B, n_a), **f32) if need_mix_grad else None
-    for g in range(G):
-        _lib.call("basd_token_weights", att_tab.data_ptr(), _dtype_code(attns[0]), mix[g].data_ptr(), L, sb, sh, sq,
-                  sk, B, H, A, int(has_cls), n_a, n, n_s, a0, a1, alam, t0, t1, lam, omega[g].data_ptr(),
-                  omega_t[g].data_ptr(), raw[g].data_ptr() if need_mix_grad else None, st)
-        _lib.call("basd_teacher_center", tok_tab.data_ptr(), _dtype_code(teachers[0]), mix[g].data_ptr(), L, tsb,
-                  tsn, tsd, B, n, d_t, g0, g1, glam, omega_t[g].data_ptr(), mu_t[g].data_ptr(), tc[g].data_ptr(), st)
-    mu_s = torch.empty((E, B, d_s), **f32)
     slabs = (d_s + 63) // 64
-    tr_part = torch.empty((E, B, slabs), **f32)
-    tr_s = torch.empty((E, B), **f32)
+    EB, GB = E * B, G * B
+    need_bwd = need_backward or grad_layers is not None
+    # kept for the backward / returned
+    omega = torch.empty((G, B, n_s), **f32)
+    mu_s = torch.empty((E, B, d_s), **f32)
     a_prime = torch.empty((E, B, n, d_s), **f32)
-    for e, x in enumerate(students):
-        _lib.call("basd_student_project", x.data_ptr(), _dtype_code(x), x.stride(0), x.stride(1), B, n_s, n, d_s,
-                  omega[0 if shared else e].data_ptr(), t0, t1, lam, r0, r1, mu_s[e].data_ptr(), tr_part[e].data_ptr(),
-                  a_prime[e].data_ptr(), st)
-    # fp64 Grams on the teacher grid, Cholesky factors, stacked product
-    g_all = torch.empty((E * B + G * B, n, n), device=dev, dtype=torch.float64)
-    _lib.call("basd_gram_f64", a_prime.data_ptr(), n * d_s, n, d_s, E * B, g_all.data_ptr(), n * n, st)
-    _lib.call("basd_gram_f64", tc.data_ptr(), n * d_t, n, d_t, G * B, g_all[E * B:].data_ptr(), n * n, st)
+    k_prime = torch.empty((E, B, n, n), **f32) if need_bwd else None
+    terms = torch.empty((4, E, B), **f32)                                # tr_s, tr_t, nuc, loss_b
+    tc = torch.empty((G, B, n, d_t), **f32)
+    g_all = torch.empty((EB + GB, n, n), device=dev, dtype=torch.float64)
     l_all = torch.empty_like(g_all)
-    _lib.call("basd_chol_f64", g_all.data_ptr(), n * n, n, E * B + G * B, l_all.data_ptr(), n * n, st)
-    l_a = l_all[:E * B]
-    g_b = g_all[E * B:]
-    l_b = l_all[E * B:]
-    if shared and E > 1:
-        l_b = l_b.repeat(E, 1, 1)
-        g_b = g_b.repeat(E, 1, 1)
-        omega_e = omega.expand(E, B, n_s).contiguous()
-    else:
-        omega_e = omega
-    W = torch.empty((E * B, n, 2 * n), **f32)      # memory == column-major (2n x n)
-    _lib.call("basd_stack_product", l_a.data_ptr(), l_b.data_ptr(), n * n, n, E * B, W.data_ptr(), 2 * n * n, st)
-    res = jacobi_onesided(W, n, want_sweeps=want_sweeps)
-    sigma, sweeps = res if want_sweeps else (res, None)
-    tr_t = torch.empty((E, B), **f32)
-    nuc = torch.empty((E, B), **f32)
-    loss_b = torch.empty((E, B), **f32)
-    k_prime = torch.empty((E, B, n, n), **f32) if need_backward else None
-    _lib.call("basd_procrustes_finalize", W.data_ptr(), 2 * n * n, sigma.data_ptr(), n, n_s, E * B, g_b.data_ptr(),
-              n * n, omega_e.data_ptr(), t0, t1, lam, tr_part.data_ptr(), slabs, tr_s.data_ptr(), tr_t.data_ptr(),
-              nuc.data_ptr(), loss_b.data_ptr(), _ptr(k_prime), st)
+    W = torch.empty((EB, n, 2 * n), **f32)      # memory == column-major (2n x n)
+    # transient fp32 scratch in one allocation
+    sizes = [GB * n, GB * d_t, EB * slabs, EB * n]
+    omega_t, mu_t, tr_part, sigma = torch.split(torch.empty((sum(sizes),), **f32), sizes)
+    ints = torch.empty((_lib.query("basd_jacobi_workspace_ints", EB, MAX_SWEEPS) + EB,), device=dev, dtype=torch.int32)
+    sweeps = None
+    if want_sweeps:
+        sweeps = ints[-EB:]
+        sweeps.zero_()
+    raw = torch.empty((G, B, n_a), **f32) if need_mix_grad else None
+    h = dx = None
+    if grad_layers is not None:
+        h = torch.empty((E, B, n, d_s), **f32)
+        dx = torch.empty((E, B, n_s, d_s), **f32)
+        grad_layers = grad_layers.contiguous().float()
+
+    args = _lib.ProcrustesArgs()
+    host_ptrs = (ctypes.c_void_p * E)(*[s.data_ptr() for s in students])
+    args.student_ptrs = _ptr_table(students).data_ptr()
+    args.student_host_ptrs = ctypes.cast(host_ptrs, ctypes.c_void_p)
+    args.s_dtype, args.s_sb, args.s_sn = _dtype_code(students[0]), students[0].stride(0), students[0].stride(1)
+    args.s_aligned = int(all(s.data_ptr() % 16 == 0 for s in students))
+    args.tok_ptrs = _ptr_table(teachers).data_ptr()
+    args.t_dtype = _dtype_code(teachers[0])
+    args.t_sb, args.t_sn, args.t_sd = teachers[0].stride()
+    args.attn_ptrs = _ptr_table(attns).data_ptr()
+    args.a_dtype = _dtype_code(attns[0])
+    args.a_sb, args.a_sh, args.a_sq, args.a_sk = attns[0].stride()
+    args.mix = mix.data_ptr()
+    (args.E, args.L, args.G, args.B, args.n_s, args.n_t, args.d_s, args.d_t, args.H, args.A, args.has_cls, args.n_a,
+     args.n, args.max_sweeps) = E, L, G, B, n_s, n_t, d_s, d_t, H, A, int(has_cls), n_a, n, MAX_SWEEPS
+    if atp:
+        args.atap0, args.atap1, args.alam = atp.tap0.data_ptr(), atp.tap1.data_ptr(), atp.lam.data_ptr()
+    if tp:
+        args.tap0, args.tap1, args.lam = tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr()
+        args.range0, args.range1 = tp.range0.data_ptr(), tp.range1.data_ptr()
+    if gt:
+        args.g0, args.g1, args.glam = gt.tap0.data_ptr(), gt.tap1.data_ptr(), gt.lam.data_ptr()
+    args.omega, args.omega_t, args.raw = omega.data_ptr(), omega_t.data_ptr(), _ptr(raw)
+    args.mu_t, args.tc, args.mu_s, args.tr_part = mu_t.data_ptr(), tc.data_ptr(), mu_s.data_ptr(), tr_part.data_ptr()
+    args.tr_s, args.tr_t, args.nuc, args.loss_b = (terms[i].data_ptr() for i in range(4))
+    args.a_prime, args.g_all, args.l_all, args.W = a_prime.data_ptr(), g_all.data_ptr(), l_all.data_ptr(), W.data_ptr()
+    args.sigma, args.jflags, args.sweeps, args.k_prime = sigma.data_ptr(), ints.data_ptr(), _ptr(sweeps), _ptr(k_prime)
+    args.h, args.dx, args.grad_layers = _ptr(h), _ptr(dx), _ptr(grad_layers)
+    _lib.call("basd_procrustes_forward_fused", ctypes.addressof(args), _stream())
+    del host_ptrs
+
     mixgrad = None
     if need_mix_grad:
-        mixgrad = dict(raw=raw, tc=tc, l_a=l_a, g_b=g_b, W=W, sigma=sigma, omega_e=omega_e, teachers=teachers,
-                       attns=attns, tok_tab=tok_tab, att_tab=att_tab, has_cls=has_cls, n_a=n_a, n=n, n_s=n_s,
-                       gather=gt, student_taps=tp, attn_taps=atp)
-    return ProcrustesContext(omega, mu_s, a_prime, k_prime, tr_s, tr_t, nuc, loss_b, sweeps, mixgrad)
+        l_a, g_b = l_all[:EB], g_all[EB:]
+        mixgrad = dict(raw=raw, tc=tc, l_a=l_a, g_b=g_b, W=W, sigma=sigma, omega_e=omega, teachers=teachers,
+                       attns=attns, tok_tab=_ptr_table(teachers), att_tab=_ptr_table(attns), has_cls=has_cls, n_a=n_a,
+                       n=n, n_s=n_s, gather=gt, student_taps=tp, attn_taps=atp)
+    return ProcrustesContext(omega, mu_s, a_prime, k_prime, terms[0], terms[1], terms[2], terms[3], sweeps, mixgrad,
+                             dx)
 
 
 def procrustes_student_grads(students: list[torch.Tensor], ctx: ProcrustesContext, grad_layers: torch.Tensor,
@@ -586,19 +619,15 @@ def procrustes_student_grads(students: list[torch.Tensor], ctx: ProcrustesContex
     h = gemm_tn(kp[0], ap[0], batch=E * B, a_batch_stride=n * n, b_batch_stride=n * d_s, krows=n, m_cols=n,
                 n_cols=d_s, split=False).view(E, B, n, d_s)
     grad_layers = grad_layers.contiguous().float()
-    grads = []
+    xs = [as_supported(x) for x in students]
+    xs = _check_common_layout([x if x.stride(2) == 1 else x.contiguous() for x in xs], "student token tensors")
+    dx = torch.empty((E, B, n_s, d_s), device=dev, dtype=torch.float32)
     gomega = torch.empty((E, B, n_s), device=dev, dtype=torch.float32) if tnorm2 is not None else None
     shared = ctx.omega.shape[0] == 1
-    for e, x in enumerate(students):
-        x = as_supported(x)
-        x = x if x.stride(2) == 1 else x.contiguous()
-        dx = torch.empty((B, n_s, d_s), device=dev, dtype=torch.float32)
-        _lib.call("basd_student_grad", x.data_ptr(), _dtype_code(x), x.stride(0), x.stride(1), B, n_s, n, d_s,
-                  ctx.omega[0 if shared else e].data_ptr(), ctx.mu_s[e].data_ptr(), h[e].data_ptr(), t0, t1, lam,
-                  grad_layers[e:e + 1].data_ptr(), 2.0 / B, dx.data_ptr(),
-                  tnorm2[e].data_ptr() if tnorm2 is not None else None,
-                  gomega[e].data_ptr() if gomega is not None else None, st)
-        grads.append(dx)
+    _lib.call("basd_student_grad_multi", _ptr_table(xs).data_ptr(), _dtype_code(xs[0]), xs[0].stride(0),
+              xs[0].stride(1), E, B, n_s, n, d_s, ctx.omega.data_ptr(), 0 if shared else B * n_s, ctx.mu_s.data_ptr(),
+              h.data_ptr(), t0, t1, lam, grad_layers.data_ptr(), 2.0 / B, dx.data_ptr(), _ptr(tnorm2), _ptr(gomega), st)
+    grads = list(dx.unbind(0))
     return (grads, gomega) if tnorm2 is not None else grads
 
 

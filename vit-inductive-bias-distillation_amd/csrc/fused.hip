@@ -1,0 +1,106 @@
+// One library call = one stage of the loss step.  The per-kernel entry points stay (tests and the general paths use
+// them); these functions queue the same launches in the same order from C, because a dozen separate FFI calls from
+// Python cost several times the launches themselves and that host time sits in front of the kernels of the caller's
+// stream (round-1 timeline: the first Procrustes kernel started 1.05 ms into a 3.5 ms step).
+#include "basd_common.h"
+#include "../../include/basd_hip.h"
+
+extern "C" {
+
+// relational.py:22-50 for all extraction layers against the (mixed) teacher, forward and -- optionally -- the student
+// gradients for given upstream gradients; see BasdProcrustesArgs in include/basd_hip.h.
+int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
+    BASD_CHECK_ARG(a && a->student_ptrs && a->tok_ptrs && a->attn_ptrs && a->mix);
+    const int E = (int)a->E, L = (int)a->L, G = (int)a->G, B = (int)a->B, n_s = (int)a->n_s, n_t = (int)a->n_t;
+    const int d_s = (int)a->d_s, d_t = (int)a->d_t, H = (int)a->H, A = (int)a->A, n_a = (int)a->n_a, n = (int)a->n;
+    BASD_CHECK_ARG(E > 0 && L > 0 && (G == 1 || G == E) && B > 0 && n == (n_s < n_t ? n_s : n_t));
+    int rc;
+#define BASD_TRY(call)            \
+    do {                          \
+        rc = (call);              \
+        if (rc != BASD_OK) return rc; \
+    } while (0)
+    // teacher side: token weights + mixed, centred teacher, once per group (G = 1: shared by all layers)
+    for (int g = 0; g < G; ++g) {
+        BASD_TRY(basd_token_weights(a->attn_ptrs, (int)a->a_dtype, a->mix + (long)g * L, L, a->a_sb, a->a_sh, a->a_sq,
+                                    a->a_sk, B, H, A, (int)a->has_cls, n_a, n, n_s, a->atap0, a->atap1, a->alam,
+                                    a->tap0, a->tap1, a->lam, a->omega + (long)g * B * n_s,
+                                    a->omega_t + (long)g * B * n, a->raw ? a->raw + (long)g * B * n_a : nullptr, st));
+        BASD_TRY(basd_teacher_center(a->tok_ptrs, (int)a->t_dtype, a->mix + (long)g * L, L, a->t_sb, a->t_sn, a->t_sd,
+                                     B, n, d_t, a->g0, a->g1, a->glam, a->omega_t + (long)g * B * n,
+                                     a->mu_t + (long)g * B * d_t, a->tc + (long)g * B * n * d_t, st));
+    }
+    // student side: all layers in one launch where the vectorised kernel applies
+    const long om_stride = G == 1 ? 0 : (long)B * n_s;
+    const int slabs = (d_s + 63) / 64;
+    rc = basd_student_project_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s,
+                                    (int)a->s_aligned, a->omega, om_stride, a->tap0, a->tap1, a->lam, a->range0,
+                                    a->range1, a->mu_s, a->tr_part, a->a_prime, st);
+    if (rc == BASD_EUNSUPPORTED) {
+        for (int e = 0; e < E; ++e)
+            BASD_TRY(basd_student_project(a->student_host_ptrs[e], (int)a->s_dtype, a->s_sb, a->s_sn, B, n_s, n, d_s,
+                                          a->omega + e * om_stride, a->tap0, a->tap1, a->lam, a->range0, a->range1,
+                                          a->mu_s + (long)e * B * d_s, a->tr_part + (long)e * B * slabs,
+                                          a->a_prime + (long)e * B * n * d_s, st));
+    } else if (rc != BASD_OK) {
+        return rc;
+    }
+    // fp64 Grams on the core grid, Cholesky factors, stacked product, SVD, per-sample terms
+    const long nn = (long)n * n;
+    const int EB = E * B, GB = G * B;
+    BASD_TRY(basd_gram_f64(a->a_prime, (long)n * d_s, n, d_s, EB, a->g_all, nn, st));
+    BASD_TRY(basd_gram_f64(a->tc, (long)n * d_t, n, d_t, GB, a->g_all + (long)EB * nn, nn, st));
+    BASD_TRY(basd_chol_f64(a->g_all, nn, n, EB + GB, a->l_all, nn, st));
+    BASD_TRY(basd_stack_product(a->l_all, a->l_all + (long)EB * nn, nn, n, EB, GB, a->W, 2 * nn, st));
+    BASD_TRY(basd_jacobi_onesided(a->W, 2 * nn, n, 2 * n, n, EB, nullptr, a->sigma, n, (int)a->max_sweeps, 0.f,
+                                  a->jflags, a->sweeps, st));
+    BASD_TRY(basd_procrustes_finalize(a->W, 2 * nn, a->sigma, n, n_s, EB, GB, a->g_all + (long)EB * nn, nn, a->omega,
+                                      a->tap0, a->tap1, a->lam, a->tr_part, slabs, a->tr_s, a->tr_t, a->nuc,
+                                      a->loss_b, a->k_prime, st));
+    // student gradients for the upstream gradients grad_layers (E floats on the device): H = K' A', then one pass
+    if (a->dx) {
+        BASD_CHECK_ARG(a->k_prime && a->h && a->grad_layers);
+        BASD_TRY(basd_gemm_tn(a->k_prime, a->a_prime, BASD_DTYPE_F32, 0, n, 1, nn, 0, d_s, 1, (long)n * d_s, 1 << 30, n,
+                              n, d_s, EB, nullptr, nullptr, 1, nullptr, a->h, d_s, (long)n * d_s, 1.f, st));
+        BASD_TRY(basd_student_grad_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s, a->omega,
+                                         om_stride, a->mu_s, a->h, a->tap0, a->tap1, a->lam, a->grad_layers,
+                                         2.0f / (float)B, a->dx, nullptr, nullptr, st));
+    }
+#undef BASD_TRY
+    return BASD_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// CU partitions.  The eigen-solve chains of a step are dependent sequences of small, latency-bound launches (a few
+// dozen workgroups that need every wave scheduled at once); the Gram / Procrustes kernels around them are throughput
+// kernels that fill every CU.  Sharing CUs, the chain kernels run 2-10x longer than alone (rocprofv3, cfg-2: rank kernel
+// 0.49 ms inside a step, 0.05 alone) and they are what the host waits for.  A HIP stream can be confined to a set of
+// CUs (hipExtStreamCreateWithCUMask): the chains get a few CUs of every XCD to themselves and the throughput kernels
+// of this library are queued on a stream masked to the complement.
+// Mask bit i enables CU (i / 8) of XCD (i % 8) on MI355X (probe: tools/probe/cumask_probe.hip; every XCD needs at least
+// one enabled CU, an XCD with an empty mask gets all of its CUs).  [cu_lo, cu_hi) = CU range inside each XCD;
+// invert != 0 selects the complement.
+// ---------------------------------------------------------------------------
+int basd_stream_create_masked(int cu_lo, int cu_hi, int invert, hipStream_t* out) {
+    BASD_CHECK_ARG(out && cu_lo >= 0 && cu_hi > cu_lo && cu_hi <= 32);
+    BASD_CHECK_ARG(!(invert && cu_lo == 0 && cu_hi == 32));
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int cu = 0; cu < 32; ++cu) {
+        const bool in = cu >= cu_lo && cu < cu_hi;
+        if (in == (invert != 0)) continue;
+        for (int xcd = 0; xcd < 8; ++xcd) {
+            const int bit = cu * 8 + xcd;
+            mask[bit >> 5] |= 1u << (bit & 31);
+        }
+    }
+    hipError_t e = hipExtStreamCreateWithCUMask(out, 8, mask);
+    return e == hipSuccess ? BASD_OK : (int)e;
+}
+
+int basd_stream_destroy(hipStream_t stream) {
+    hipError_t e = hipStreamDestroy(stream);
+    return e == hipSuccess ? BASD_OK : (int)e;
+}
+
+}  // extern "C"

@@ -441,6 +441,16 @@ extern "C" {
 
 int basd_jacobi_workspace_ints(int batch, int max_sweeps) { return 2 * batch * max_sweeps; }
 
+// Test / tuning hook: lanes per column pair of the LDS-resident solver -- 0 / 16 = one DPP row per pair (default),
+// 4 = one quad per pair for stacked matrices (measured on MI355X, 1024 x (98 x 49): 0.84 ms against 0.87 -- the fewer
+// instruction issues are paid back in per-wave latency, so it is not selected automatically).  Process-wide.
+static int g_jacobi_lanes = 0;
+int basd_jacobi_tuning(int lanes_per_pair) {
+    if (lanes_per_pair != 0 && lanes_per_pair != 4 && lanes_per_pair != 16) return BASD_EINVAL;
+    g_jacobi_lanes = lanes_per_pair;
+    return BASD_OK;
+}
+
 // One-sided Jacobi on `batch` column-major matrices (rows_tot x n, leading dim rows_tot).
 //   n_arr (device, nullable): per-matrix order for square problems (rows = n_arr[m]); the
 //   storage still uses rows_tot / batch_stride of the largest problem.
@@ -464,7 +474,7 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
     BASD_CHECK_ARG(!(stacked && n_arr));
 
     // ---- LDS-resident, throughput shape: large batches of small stacked matrices, 4 lanes per column pair ----
-    if (stacked && batch >= 256 && n_even >= 8) {
+    if (stacked && n_even >= 8 && g_jacobi_lanes == 4) {
         const int dot8 = (rows_dot + 7) / 8, ride8 = (rows_tot - rows_dot + 7) / 8;
         const int half8 = dot8 > ride8 ? dot8 : ride8;            // 8-row chunks per half; DOT = 2 * half8 elements / lane
         static const int q_dot[] = {8, 12, 14, 16};

@@ -247,6 +247,90 @@ __global__ void __launch_bounds__(256) student_project_lds_kernel(const T* __res
     }
 }
 
+// All E extraction layers in ONE launch, 16-byte LDS accesses.  grid = (ceil(D/64), B, E), block = 256 =
+// 16 feature quads x 16 row groups.  The (n_s x 64) slab is staged once by coalesced 16-byte loads (256 contiguous
+// bytes per row: a wave's ds_write_b128 / ds_read_b128 of 16 lanes per row are conflict-free by construction);
+// thread (fq, rg) then owns features 4 fq .. 4 fq + 3 and rows rg, rg + 16, ...: every sweep reads float4s, a sixth
+// of the LDS instructions of the 4-byte version above (which was bound by LDS issue at 0.9 TB/s of HBM traffic).
+// x_ptrs: device table of E base pointers (same strides); omega + e * omega_e_stride; outputs are (E, B, ...).
+template <typename T>
+__global__ void __launch_bounds__(256) student_project_v4_kernel(const void* const* __restrict__ x_ptrs, long sb,
+                                                                 long sn, int n_s, int n_t, int D,
+                                                                 const float* __restrict__ omega, long omega_e_stride,
+                                                                 const int* __restrict__ tap0,
+                                                                 const int* __restrict__ tap1,
+                                                                 const float* __restrict__ lam,
+                                                                 const int* __restrict__ range0,
+                                                                 const int* __restrict__ range1,
+                                                                 float* __restrict__ mu_out,
+                                                                 float* __restrict__ tr_part, float* __restrict__ Ap) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;                      // n_s x 64 slab, row-major
+    float* w = sm + (long)n_s * 64;      // n_s
+    __shared__ __attribute__((aligned(16))) float red[16][64];
+    __shared__ __attribute__((aligned(16))) float mu[64];
+    __shared__ float scratch[32];
+    const int b = blockIdx.y, e = blockIdx.z, B = gridDim.y, d0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int fq = tid & 15, rg = tid >> 4, c4 = 4 * fq;
+    const bool live = d0 + c4 < D;       // D % 4 == 0: the quad is inside or outside
+    const T* Xb = (const T*)x_ptrs[e] + (long)b * sb + d0;
+    const float* om = omega + (long)e * omega_e_stride + (long)b * n_s;
+    for (int n = tid; n < n_s; n += 256) w[n] = om[n];
+    for (int n = rg; n < n_s; n += 16) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) v = ld4f(Xb + (long)n * sn + c4);
+        *(float4*)(xs + n * 64 + c4) = v;
+    }
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = rg; n < n_s; n += 16) {
+        const float4 v = *(const float4*)(xs + n * 64 + c4);
+        const float wn = w[n];
+        acc.x = fmaf(wn, v.x, acc.x); acc.y = fmaf(wn, v.y, acc.y);
+        acc.z = fmaf(wn, v.z, acc.z); acc.w = fmaf(wn, v.w, acc.w);
+    }
+    *(float4*)(&red[rg][c4]) = acc;
+    __syncthreads();
+    if (tid < 64) {
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) m += red[q][tid];
+        mu[tid] = m;
+        if (d0 + tid < D) mu_out[((long)e * B + b) * D + d0 + tid] = m;
+    }
+    __syncthreads();
+    const float4 m4 = *(const float4*)(mu + c4);
+    // trace: sum_n w_n (x_n - mu)^2 over this slab
+    float part = 0.f;
+    if (live)
+        for (int n = rg; n < n_s; n += 16) {
+            const float4 v = *(const float4*)(xs + n * 64 + c4);
+            const float cx = v.x - m4.x, cy = v.y - m4.y, cz = v.z - m4.z, cw = v.w - m4.w;
+            part = fmaf(w[n], fmaf(cx, cx, fmaf(cy, cy, fmaf(cz, cz, cw * cw))), part);
+        }
+    const float tr = block_sum(part, scratch);
+    if (tid == 0) tr_part[((long)e * B + b) * gridDim.x + blockIdx.x] = tr;
+    // A'[j, d] = sum_n I[n, j] w_n (x_n - mu)
+    if (!live) return;
+    float* Ab = Ap + ((long)e * B + b) * n_t * D + d0 + c4;
+    for (int j = rg; j < n_t; j += 16) {
+        const int n0 = range0 ? range0[j] : j, n1 = range1 ? range1[j] : j + 1;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = n0; n < n1; ++n) {
+            float coef = 1.f;
+            if (tap0) {
+                const float l1 = lam[n];
+                coef = (tap0[n] == j ? 1.f - l1 : 0.f) + (tap1[n] == j ? l1 : 0.f);
+            }
+            const float cw = coef * w[n];
+            const float4 v = *(const float4*)(xs + n * 64 + c4);
+            a.x = fmaf(cw, v.x - m4.x, a.x); a.y = fmaf(cw, v.y - m4.y, a.y);
+            a.z = fmaf(cw, v.z - m4.z, a.z); a.w = fmaf(cw, v.w - m4.w, a.w);
+        }
+        *(float4*)(Ab + (long)j * D) = a;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Teacher side: mix the L layers, (optionally) resample to the core grid, weighted-centre.
 //   Tbar[b, r, :] = sum_l mix_l T_l[b, r, :]                               (layer_selector.py:110-111)
@@ -462,12 +546,13 @@ __global__ void __launch_bounds__(1024) chol_f64_kernel(const double* __restrict
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) stack_product_kernel(const double* __restrict__ La,
                                                             const double* __restrict__ Lb, long l_batch_stride,
-                                                            int n, float* __restrict__ W, long w_batch_stride) {
+                                                            int n, float* __restrict__ W, long w_batch_stride,
+                                                            int lb_period) {
     const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * n) return;
     const int i = idx / n, j = idx - i * n;   // consecutive threads: consecutive j
     const double* A = La + (long)b * l_batch_stride;
-    const double* B = Lb + (long)b * l_batch_stride;
+    const double* B = Lb + (long)(b % lb_period) * l_batch_stride;   // one teacher factor for all extraction layers
     double acc = 0.;
     for (int k = (i > j ? i : j); k < n; ++k) acc = fma(A[(long)k * n + i], B[(long)k * n + j], acc);
     float* Wb = W + (long)b * w_batch_stride;
@@ -484,7 +569,7 @@ __global__ void __launch_bounds__(256) procrustes_finalize_kernel(
     const double* __restrict__ Gb, long g_batch_stride, const float* __restrict__ omega,
     const int* __restrict__ tap0, const int* __restrict__ tap1, const float* __restrict__ lam,
     const float* __restrict__ tr_s, int tr_slabs, float* __restrict__ tr_s_out, float* __restrict__ tr_t_out,
-    float* __restrict__ nuc_out, float* __restrict__ loss_out, float* __restrict__ Kp) {
+    float* __restrict__ nuc_out, float* __restrict__ loss_out, float* __restrict__ Kp, int t_period) {
     extern __shared__ float sm[];
     float* isig = sm;                      // n : 1/sigma_j or 0 when truncated
     __shared__ float red[32];
@@ -505,10 +590,11 @@ __global__ void __launch_bounds__(256) procrustes_finalize_kernel(
     const float thr = smax * (float)n * 1.1920929e-7f;
     for (int j = tid; j < n; j += 256) isig[j] = sg[j] > thr ? 1.f / sg[j] : 0.f;
     // teacher trace on the student grid: sum_n w_n |sum_j I[n,j] tc_j|^2, from the fp64 Gram
-    const double* G = Gb + (long)b * g_batch_stride;
+    const int bt = b % t_period;          // teacher-side sample (Gram, weights) shared by the extraction layers
+    const double* G = Gb + (long)bt * g_batch_stride;
     double part = 0.;
     for (int s = tid; s < n_s; s += 256) {
-        const double w = (double)omega[(long)b * n_s + s];
+        const double w = (double)omega[(long)bt * n_s + s];
         if (tap0) {
             const int i0 = tap0[s], i1 = tap1[s];
             const double l1 = (double)lam[s], l0 = 1. - l1;
@@ -552,9 +638,12 @@ __global__ void __launch_bounds__(256) procrustes_finalize_kernel(
 // Optionally also d loss_b / d omega_s = |x_c|^2 + |t_hat_c|^2 - 2 x_c . interp(H)_s  (un-scaled),
 // needed only when the mixing weights carry a gradient (multi-layer teachers).
 // ---------------------------------------------------------------------------
+// blockIdx.z = extraction layer e when x_ptrs is given (all layers in one launch: X = nullptr, operands are (E, B, ...)
+// with omega advanced by omega_e_stride per layer); a single layer otherwise (x_ptrs = nullptr, gridDim.z = 1).
 template <typename T>
-__global__ void __launch_bounds__(128) student_grad_kernel(const T* __restrict__ X, long sb, long sn, int n_s, int n_t,
-                                                           int D, const float* __restrict__ omega,
+__global__ void __launch_bounds__(128) student_grad_kernel(const T* __restrict__ X, const void* const* __restrict__ x_ptrs,
+                                                           long sb, long sn, int n_s, int n_t,
+                                                           int D, const float* __restrict__ omega, long omega_e_stride,
                                                            const float* __restrict__ mu, const float* __restrict__ H,
                                                            const int* __restrict__ tap0, const int* __restrict__ tap1,
                                                            const float* __restrict__ lam,
@@ -562,9 +651,11 @@ __global__ void __launch_bounds__(128) student_grad_kernel(const T* __restrict__
                                                            float* __restrict__ dX, const float* __restrict__ tnorm2,
                                                            float* __restrict__ gomega) {
     __shared__ float red[32];
-    const int s = blockIdx.x, b = blockIdx.y;
-    const float coef = scale_ptr[0] * scale_const * omega[(long)b * n_s + s];
-    const T* x = X + (long)b * sb + (long)s * sn;
+    const int s = blockIdx.x, e = blockIdx.z;
+    const long B = gridDim.y, b = (long)e * B + blockIdx.y;      // sample index into the (E, B, ...) operands
+    if (x_ptrs) X = (const T*)x_ptrs[e];
+    const float coef = scale_ptr[e] * scale_const * omega[(long)e * omega_e_stride + (long)blockIdx.y * n_s + s];
+    const T* x = X + (long)blockIdx.y * sb + (long)s * sn;
     const float* m = mu + (long)b * D;
     int i0 = s, i1 = s;
     float l1 = 0.f;
@@ -739,23 +830,24 @@ int basd_chol_f64(const double* g, long g_batch_stride, int n, int batch, double
     BASD_RETURN_LAST();
 }
 
-int basd_stack_product(const double* la, const double* lb, long l_batch_stride, int n, int batch, float* w,
-                       long w_batch_stride, hipStream_t stream) {
-    BASD_CHECK_ARG(la && lb && w && n > 0 && batch > 0);
-    stack_product_kernel<<<dim3((n * n + 255) / 256, batch), 256, 0, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride);
+int basd_stack_product(const double* la, const double* lb, long l_batch_stride, int n, int batch, int lb_period,
+                       float* w, long w_batch_stride, hipStream_t stream) {
+    BASD_CHECK_ARG(la && lb && w && n > 0 && batch > 0 && lb_period > 0);
+    stack_product_kernel<<<dim3((n * n + 255) / 256, batch), 256, 0, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride, lb_period);
     BASD_RETURN_LAST();
 }
 
 // relational.py:45-50 per sample: tr_t, nuclear norm, loss_b = tr_s + tr_t - 2 nuc; K' for backward (nullable).
 int basd_procrustes_finalize(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
-                             const double* gb, long g_batch_stride, const float* omega, const int* tap0,
+                             int t_period, const double* gb, long g_batch_stride, const float* omega, const int* tap0,
                              const int* tap1, const float* lam, const float* tr_s_part, int tr_slabs, float* tr_s,
                              float* tr_t, float* nuc, float* loss, float* k_prime, hipStream_t stream) {
     BASD_CHECK_ARG(w && sigma && gb && omega && tr_s_part && tr_s && tr_t && nuc && loss && n > 0 && batch > 0 && tr_slabs > 0);
+    BASD_CHECK_ARG(t_period > 0);
     const size_t lds = sizeof(float) * ((size_t)n + (k_prime ? (size_t)n * n : 0));
     if (lds > 156 * 1024) return BASD_EUNSUPPORTED;
     (void)hipFuncSetAttribute((const void*)procrustes_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    procrustes_finalize_kernel<<<batch, 256, lds, stream>>>(w, w_batch_stride, sigma, n, n_s, gb, g_batch_stride, omega, tap0, tap1, lam, tr_s_part, tr_slabs, tr_s, tr_t, nuc, loss, k_prime);
+    procrustes_finalize_kernel<<<batch, 256, lds, stream>>>(w, w_batch_stride, sigma, n, n_s, gb, g_batch_stride, omega, tap0, tap1, lam, tr_s_part, tr_slabs, tr_s, tr_t, nuc, loss, k_prime, t_period);
     BASD_RETURN_LAST();
 }
 
@@ -768,11 +860,59 @@ int basd_student_grad(const void* x, int dtype, long sb, long sn, int B, int n_s
     BASD_CHECK_ARG((gomega == nullptr) || (tnorm2 != nullptr));
     const dim3 grid(n_s, B);
     if (dtype == BASD_DTYPE_F32)
-        student_grad_kernel<float><<<grid, 128, 0, stream>>>((const float*)x, sb, sn, n_s, n_t, D, omega, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx, tnorm2, gomega);
+        student_grad_kernel<float><<<grid, 128, 0, stream>>>((const float*)x, nullptr, sb, sn, n_s, n_t, D, omega, 0, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx, tnorm2, gomega);
     else if (dtype == BASD_DTYPE_BF16)
-        student_grad_kernel<__hip_bfloat16><<<grid, 128, 0, stream>>>((const __hip_bfloat16*)x, sb, sn, n_s, n_t, D, omega, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx, tnorm2, gomega);
+        student_grad_kernel<__hip_bfloat16><<<grid, 128, 0, stream>>>((const __hip_bfloat16*)x, nullptr, sb, sn, n_s, n_t, D, omega, 0, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx, tnorm2, gomega);
     else
         return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+// The same for all E extraction layers in one launch: x_ptrs device table of E base pointers (common strides),
+// omega + e * omega_e_stride (0: one weight vector for all layers), mu / h / dx / tnorm2 / gomega laid out (E, B, ...),
+// scale_ptr[e] the upstream gradient of layer e.
+int basd_student_grad_multi(const void* const* x_ptrs, int dtype, long sb, long sn, int E, int B, int n_s, int n_t,
+                            int D, const float* omega, long omega_e_stride, const float* mu, const float* h,
+                            const int* tap0, const int* tap1, const float* lam, const float* scale_ptr,
+                            float scale_const, float* dx, const float* tnorm2, float* gomega, hipStream_t stream) {
+    BASD_CHECK_ARG(x_ptrs && omega && mu && h && scale_ptr && dx && E > 0 && B > 0 && n_s > 0 && n_t > 0 && D > 0);
+    BASD_CHECK_ARG((gomega == nullptr) || (tnorm2 != nullptr));
+    BASD_CHECK_ARG(E <= 65535 && B <= 65535);
+    const dim3 grid(n_s, B, E);
+    if (dtype == BASD_DTYPE_F32)
+        student_grad_kernel<float><<<grid, 128, 0, stream>>>(nullptr, x_ptrs, sb, sn, n_s, n_t, D, omega, omega_e_stride, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx, tnorm2, gomega);
+    else if (dtype == BASD_DTYPE_BF16)
+        student_grad_kernel<__hip_bfloat16><<<grid, 128, 0, stream>>>(nullptr, x_ptrs, sb, sn, n_s, n_t, D, omega, omega_e_stride, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx, tnorm2, gomega);
+    else
+        return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+// basd_student_project for all E extraction layers in one launch (x_ptrs: device table; omega + e * omega_e_stride;
+// mu (E, B, D), tr_s (E, B, ceil(D/64)), a_prime (E, B, n_t, D)).  Returns BASD_EUNSUPPORTED where the vectorised,
+// LDS-staged kernel does not apply (rows not 16-byte aligned, slab over 64 KB): call basd_student_project per layer.
+int basd_student_project_multi(const void* const* x_ptrs, int dtype, long sb, long sn, int E, int B, int n_s, int n_t,
+                               int D, int ptrs_16B_aligned, const float* omega, long omega_e_stride, const int* tap0,
+                               const int* tap1, const float* lam, const int* range0, const int* range1, float* mu,
+                               float* tr_s, float* a_prime, hipStream_t stream) {
+    BASD_CHECK_ARG(x_ptrs && omega && mu && tr_s && a_prime && E > 0 && B > 0 && n_s > 0 && n_t > 0 && D > 0);
+    BASD_CHECK_ARG((n_t == n_s) == (tap0 == nullptr));
+    BASD_CHECK_ARG(E <= 65535 && B <= 65535);
+    const int esz = dtype == BASD_DTYPE_F32 ? 4 : 2;
+    const size_t lds = sizeof(float) * ((size_t)n_s * 64 + n_s);
+    const bool ok = ptrs_16B_aligned && D % 4 == 0 && (sb * esz) % 16 == 0 && (sn * esz) % 16 == 0 &&
+                    (esz == 4 || D % 8 == 0) && lds <= 64 * 1024;
+    if (!ok) return BASD_EUNSUPPORTED;
+    const dim3 grid((D + 63) / 64, B, E);
+    if (dtype == BASD_DTYPE_F32) {
+        (void)hipFuncSetAttribute((const void*)student_project_v4_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        student_project_v4_kernel<float><<<grid, 256, lds, stream>>>(x_ptrs, sb, sn, n_s, n_t, D, omega, omega_e_stride, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+    } else if (dtype == BASD_DTYPE_BF16) {
+        (void)hipFuncSetAttribute((const void*)student_project_v4_kernel<__hip_bfloat16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        student_project_v4_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>(x_ptrs, sb, sn, n_s, n_t, D, omega, omega_e_stride, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);
+    } else {
+        return BASD_EINVAL;
+    }
     BASD_RETURN_LAST();
 }
 

@@ -356,17 +356,29 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
 // n <= 64 * CPL: the whole factorisation (j0 = 0, pend = nullptr) -- nothing spins anywhere.
 // n >  64 * CPL: tridiag_kernel does steps [0, j0) and hands over the pending update (pend: v, w of step j0 - 1).
 // ---------------------------------------------------------------------------
+// Marchenko-Pastur rank of the tridiagonal (dz, ez) by the whole workgroup (defined below, next to the Sturm count).
+struct MpRankOut {
+    int* rank_out;        // (count) device
+    int* host_mirror;     // nullable: pinned host memory, count + 8 ints
+    const int* status;    // nullable: 8 status words of the factorisation, copied behind the ranks
+    double factor;
+    int cap, count;
+};
+__device__ __forceinline__ void mp_rank_block(const float* dz, const float* ez, int n, int z, const MpRankOut& o,
+                                              float* thr_out);
+
 template <int WAVES, int RPW, int CPL>
 __global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restrict__ A, long a_batch_stride, int n,
                                                                   int j0, const float* __restrict__ pend,
                                                                   float* __restrict__ d, float* __restrict__ e,
                                                                   float* __restrict__ tau_out,
-                                                                  float* __restrict__ Vh) {
+                                                                  float* __restrict__ Vh, MpRankOut rk) {
     constexpr int MMAX = 64 * CPL;
     static_assert(WAVES * RPW >= MMAX, "every row needs an owner");
     static_assert(WAVES * 64 >= MMAX, "one thread per column in the vector phases");
     __builtin_amdgcn_s_setprio(3);
     __shared__ float u[MMAX], v[MMAX], w[MMAX], cap[MMAX], pw[MMAX], col[MMAX];
+    __shared__ float dloc[MMAX], eloc[MMAX];      // d, e of the local steps (for the rank at the end)
     __shared__ float part[WAVES][MMAX];
     __shared__ float red[2][16];
     const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -422,8 +434,8 @@ __global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restr
             tau = (beta - alpha) / beta;
         }
         if (tid == 0) {
-            dz[j0 + jl] = col[jl];
-            ez[j0 + jl] = beta;
+            dz[j0 + jl] = dloc[jl] = col[jl];
+            ez[j0 + jl] = eloc[jl] = beta;
             tz[j0 + jl] = tau;
         }
         const float scal = tau != 0.f ? 1.f / (alpha - beta) : 0.f;
@@ -510,11 +522,26 @@ __global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restr
         if (jl + 1 < m - 1) store_reflector(jl + 1);
     }
     if (tid == 0) {
-        dz[n - 1] = col[m - 1];
-        ez[n - 1] = 0.f;
+        dz[n - 1] = dloc[m - 1] = col[m - 1];
+        ez[n - 1] = eloc[m - 1] = 0.f;
         tz[n - 1] = 0.f;
     }
     for (int c = tid; c < n; c += 64 * WAVES) Vz[(long)(n - 1) * n + c] = 0.f;
+    // The Marchenko-Pastur rank of the first `count` matrices of the batch right here: the host is waiting for it, and
+    // this workgroup already owns a CU -- a separate launch would queue for wave slots behind the throughput kernels
+    // of the other streams (rocprofv3, cfg-2: 0.17-0.49 ms inside a step for 0.05 ms of work).  The tridiagonal is
+    // staged in LDS (the partials buffer is free now); entries of the first stage come from global memory.
+    if (rk.rank_out && z < rk.count && 2 * n <= WAVES * MMAX) {
+        __syncthreads();
+        float* dl = &part[0][0];
+        float* el = dl + n;
+        for (int c = tid; c < n; c += 64 * WAVES) {
+            dl[c] = c < j0 ? dz[c] : dloc[c - j0];
+            el[c] = c < j0 ? ez[c] : eloc[c - j0];
+        }
+        __syncthreads();
+        mp_rank_block(dl, el, n, z, rk, nullptr);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -860,16 +887,10 @@ __global__ void __launch_bounds__(256) backtransform_kernel(const float* __restr
 // the eigenvectors.  Same arithmetic as sturm_bisect_kernel / mp_rank_kernel (pivmin rule, convergence rule,
 // threshold rounded to fp32); "eigenvalue > threshold" is counted as n - #(eigenvalues < threshold).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __restrict__ d, const float* __restrict__ e,
-                                                               int n, double factor, int cap,
-                                                               int* __restrict__ rank_out, float* __restrict__ thr_out,
-                                                               const int* __restrict__ status,
-                                                               int* __restrict__ host_mirror) {
-    __builtin_amdgcn_s_setprio(3);     // the host is waiting for this kernel: see tridiag_kernel
+__device__ __forceinline__ void mp_rank_block(const float* dz, const float* ez, int n, int z, const MpRankOut& o,
+                                              float* thr_out) {
     __shared__ float red3[3][16];
-    const int z = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
-    const float* dz = d + (long)z * n;
-    const float* ez = e + (long)z * n;
+    const int tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6;
     float lo = 3.4e38f, hi = -3.4e38f, emax = 0.f;
     for (int i = tid; i < n; i += nthr) {
         const float di = dz[i];
@@ -917,16 +938,27 @@ __global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __re
         if (stalled || b - a <= 2.f * eps * fmaxf(fabsf(a), fabsf(b)) + pivmin) break;   // uniform
     }
     const float sigma2 = 0.5f * (a + b);
-    const float lam = (float)((double)sigma2 * factor);
+    const float lam = (float)((double)sigma2 * o.factor);
     const int above = n - sturm_count(dz, ez, n, lam, pivmin);     // whole waves: the count broadcasts across lanes
     if (tid == 0) {
-        rank_out[z] = above < cap ? above : cap;
+        o.rank_out[z] = above < o.cap ? above : o.cap;
         if (thr_out) thr_out[z] = lam;
         // the host's copy, written straight into pinned memory (no copy engine round on the critical path):
-        // [ranks x batch, 8 status words of the factorisation]
-        if (host_mirror) host_mirror[z] = above < cap ? above : cap;
+        // [ranks x count, 8 status words of the factorisation]
+        if (o.host_mirror) o.host_mirror[z] = above < o.cap ? above : o.cap;
     }
-    if (host_mirror && status && z == 0 && tid < 8) host_mirror[gridDim.x + tid] = status[tid];
+    if (o.host_mirror && o.status && z == 0 && tid < 8) o.host_mirror[o.count + tid] = o.status[tid];
+}
+
+__global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __restrict__ d, const float* __restrict__ e,
+                                                               int n, double factor, int cap,
+                                                               int* __restrict__ rank_out, float* __restrict__ thr_out,
+                                                               const int* __restrict__ status,
+                                                               int* __restrict__ host_mirror) {
+    __builtin_amdgcn_s_setprio(3);     // the host is waiting for this kernel: see tridiag_kernel
+    const int z = blockIdx.x;
+    const MpRankOut o{rank_out, host_mirror, status, factor, cap, (int)gridDim.x};
+    mp_rank_block(d + (long)z * n, e + (long)z * n, n, z, o, thr_out);
 }
 
 
@@ -1093,8 +1125,8 @@ long basd_tridiag_workspace_bytes(int n, int batch) {
     return (long)batch * 2 * n * 16 + (long)batch * 2 * n * 4 + 32;
 }
 
-int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
-                 void* work, hipStream_t stream) {
+static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
+                        void* work, MpRankOut rk, hipStream_t stream) {
     BASD_CHECK_ARG(a && d && e && tau && vh && work && n > 1 && batch > 0);
     BASD_CHECK_ARG((((uintptr_t)work) & 15) == 0);
     if (n > 4096) return BASD_EUNSUPPORTED;
@@ -1127,9 +1159,33 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
         hipError_t me = hipMemsetAsync(err, 0, 32, stream);        // no shared stage: the status words stay clean
         if (me != hipSuccess) return (int)me;
     }
-    if (tail)
-        tridiag_tail_kernel<16, 16, 4><<<batch, 1024, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh);
+    rk.status = err;
+    const bool fused_rank = tail && rk.rank_out && 2 * n <= 16 * TRI_TAIL_MAX;
+    if (tail) {
+        MpRankOut in_tail = rk;
+        if (!fused_rank) in_tail.rank_out = nullptr;
+        tridiag_tail_kernel<16, 16, 4><<<batch, 1024, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
+    }
+    if (rk.rank_out && !fused_rank)
+        tridiag_mp_rank_kernel<<<rk.count, 1024, 0, stream>>>(d, e, n, rk.factor, rk.cap, rk.rank_out, nullptr, rk.host_mirror ? err : nullptr, rk.host_mirror);
     BASD_RETURN_LAST();
+}
+
+int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
+                 void* work, hipStream_t stream) {
+    return tridiag_impl(a, a_batch_stride, n, batch, d, e, tau, vh, work, MpRankOut{nullptr, nullptr, nullptr, 0., 0, 0}, stream);
+}
+
+// basd_tridiag + the Marchenko-Pastur ranks (basd_tridiag_mp_rank) of the FIRST rank_count matrices of the batch, computed
+// by the workgroup that finishes the factorisation (no separate launch on the path the host waits for).  host_mirror
+// (nullable): pinned host memory of rank_count + 8 ints -- the ranks, then the factorisation's 8 status words.
+int basd_tridiag_ranked(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
+                        void* work, int rank_count, double factor, int cap, int* rank_out, int* host_mirror,
+                        hipStream_t stream) {
+    BASD_CHECK_ARG(rank_out && rank_count > 0 && rank_count <= batch);
+    if (n > 8192) return BASD_EUNSUPPORTED;
+    return tridiag_impl(a, a_batch_stride, n, batch, d, e, tau, vh, work,
+                        MpRankOut{rank_out, host_mirror, nullptr, factor, cap, rank_count}, stream);
 }
 
 // All eigenvalues (descending) of the tridiagonals by Sturm bisection.
