@@ -261,8 +261,9 @@ def test_rank_zero_raises_like_the_reference(sync_ranks):
     """A teacher whose projected Gram has a flat spectrum has Marchenko-Pastur rank 0 (no eigenvalue exceeds
     median * (1 + sqrt(q))^2); the reference then produces NaN mixing weights and torch.linalg.svd raises
     LinAlgError.  Same class here, and the oracle agrees on the rank.
-    ``sync_ranks`` (BASD_RANK_READBACK=sync): raised inside the call, the reference's timing; default (deferred
-    read-back, one teacher layer): raised by the first reader of ``subspace_ranks`` or by the next forward."""
+    ``sync_ranks`` (the default): raised inside the call, the reference's timing; deferred read-back
+    (BASD_RANK_READBACK=deferred, one teacher layer): raised by the first reader of ``subspace_ranks`` or by the
+    next forward."""
     shape = synth.LossShape("flat", 4, 16, 32, 12, 16, 48, 1, 1, False, 10)
     mod = _module(shape, 0.0)
     mod.sync_ranks = sync_ranks

@@ -455,6 +455,9 @@ class GrassmannianLayerSelector(nn.Module):
                         # status word of this factorisation: read by the host one step later (it never waits for
                         # the student chain)
                         st["student_status"] = self._queue_readback([s_ts.err], "student")
+                    elif eig_s is None:
+                        # same stream as the teacher chain that follows: this copy is complete when the rank event is
+                        st["student_status_now"] = self._queue_readback([s_ts.err], "student")
                     ops.tridiag_spectrum(s_ts)
                 st["s_ts"] = s_ts
 
@@ -535,6 +538,9 @@ class GrassmannianLayerSelector(nn.Module):
                 status.append(int(pending[0][0]))
             if "student_status" in st:
                 self._pending_status = st["student_status"]
+            if "student_status_now" in st:         # multi-layer teachers: the student eigenvectors feed this loss
+                st["student_status_now"][1].synchronize()
+                status.append(int(st["student_status_now"][0][0]))
         else:
             errs = [st[k].err for k in ("t_ts", "s_ts") if k in st and st[k].err is not None]
             host = torch.cat([ranks_dev.to(torch.int32), *errs]).tolist() if errs else ranks_dev.tolist()
@@ -783,9 +789,10 @@ class BASDLoss(nn.Module):
         )
         self.last_components: dict[str, torch.Tensor] = {}
         self._side_streams: dict = {}
-        # When the selector does not feed the loss (one teacher layer) the host need not wait for the ranks
-        # inside forward; BASD_RANK_READBACK=sync restores the reference's timing (read and raise in the call).
-        self.sync_ranks = os.environ.get("BASD_RANK_READBACK", "deferred") == "sync"
+        # The reference reads the ranks (and raises on rank 0) inside forward; so do we.  BASD_RANK_READBACK=deferred
+        # (or ``sync_ranks = False``): with one teacher layer the ranks do not feed the loss, the read-back is then
+        # completed by the next forward / the first reader of ``subspace_ranks`` and consecutive steps may overlap.
+        self.sync_ranks = os.environ.get("BASD_RANK_READBACK", "sync") != "deferred"
         # CU partition "a,b" (CUs per XCD for the teacher chain / the student chain), "0" = off; see _partition
         part = [int(v) for v in os.environ.get("BASD_CU_PARTITION", "0").split(",")]
         self.cu_partition = tuple((part + [0])[:2]) if part[0] > 0 else None

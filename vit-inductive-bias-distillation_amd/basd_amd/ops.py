@@ -463,6 +463,10 @@ def _device_consts(values: tuple, dtype: torch.dtype, device: torch.device) -> t
     t = _CONSTS.get(key)
     if t is None:
         if len(_CONSTS) > 512:
+            # The tables are read by kernels on several streams (chains, tail, caller) without record_stream: before
+            # their memory may be handed out again every queued reader must be done.  Rare (input addresses churning:
+            # once per ~100 steps at five new tables a step), so a device-wide wait is the simple safe choice.
+            torch.cuda.synchronize(device)
             _CONSTS.clear()
         t = torch.tensor(values, dtype=dtype).to(device)
         _CONSTS[key] = t

@@ -149,12 +149,23 @@ template <typename TA, bool VEC_A>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand B, int M, int N, int K,
                                                       float* __restrict__ C, long ldc, long c_batch_stride,
                                                       float scale, const float* __restrict__ bias, float beta,
-                                                      float* __restrict__ colsum_part) {
+                                                      float* __restrict__ colsum_part, int nx, int ny) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 128 * NT_LD];
     float* tA = lds;
     float* tB = lds + 128 * NT_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // Tile of this workgroup.  1-D grids (gridDim.y == 1 < ny) are decoded XCD-aware: workgroup ids are dealt round-
+    // robin over the 8 XCDs, so the nx column tiles of one row tile get ids of ONE residue class mod 8 and adjacent
+    // slots -- the row tile's A panel (the large, often strided operand) then crosses the fabric into one L2 only
+    // (teacher projection at cfg-2, nx = 3: 464 MB of HBM-side traffic per launch before, for 125 MB of operands).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.y == 1 && ny > 1) {
+        const int r = bx & 7, s = bx >> 3;
+        bx = s % nx;
+        by = (s / nx) * 8 + r;
+        if (by >= ny) return;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     A.ptr = (const TA*)A.ptr + (long)blockIdx.z * A.batch_stride;
     B.ptr = (const float*)B.ptr + (long)blockIdx.z * B.batch_stride;
     C += (long)blockIdx.z * c_batch_stride;
@@ -227,7 +238,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand
         }
         __syncthreads();
         if (tid < 128 && n0 + tid < N)
-            colsum_part[((long)blockIdx.z * gridDim.y + blockIdx.y) * N + n0 + tid] = lds[tid] + lds[128 + tid];
+            colsum_part[((long)blockIdx.z * ny + by) * N + n0 + tid] = lds[tid] + lds[128 + tid];
     }
 }
 
@@ -689,14 +700,17 @@ int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, in
     BASD_CHECK_ARG(!col_mean || colsum_part);
     GemmOperand A{a, a_sb, a_sn, a_sd, a_rows_per_batch, a_batch_stride};
     GemmOperand B{b, 0, ldb, 1, 1 << 30, b_batch_stride};
-    const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+    const int nx = (N + BN - 1) / BN, ny = (M + BM - 1) / BM;
+    // many row tiles x several column tiles: 1-D grid with the XCD-aware decode (see the kernel); else the plain 3-D grid
+    const bool xcd = nx > 1 && ny >= 16;
+    const dim3 grid = xcd ? dim3(8 * nx * ((ny + 7) / 8), 1, batch) : dim3(nx, ny, batch);
     if (a_dtype == BASD_DTYPE_F32) {
         const bool vec = a_sd == 1 && aligned16(a) && a_sb % 4 == 0 && a_sn % 4 == 0 && a_batch_stride % 4 == 0;
-        if (vec) gemm_nt_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part);
-        else gemm_nt_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part);
+        if (vec) gemm_nt_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
+        else gemm_nt_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
     } else if (a_dtype == BASD_DTYPE_BF16) {
-        if (a_sd == 1) gemm_nt_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part);
-        else gemm_nt_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part);
+        if (a_sd == 1) gemm_nt_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
+        else gemm_nt_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
     } else {
         return BASD_EINVAL;
     }

@@ -430,15 +430,17 @@ __global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restr
         float beta = alpha;
         tau = 0.f;
         if (xn2 > 0.f) {
-            beta = -copysignf(sqrtf(fmaf(alpha, alpha, xn2)), alpha);
-            tau = (beta - alpha) / beta;
+            // 1-ulp hardware sqrt / reciprocal: IEEE sqrtf and division are ~30-instruction software sequences, three
+            // of them in a row on the dependent chain of every step
+            beta = -copysignf(__builtin_amdgcn_sqrtf(fmaf(alpha, alpha, xn2)), alpha);
+            tau = (beta - alpha) * __builtin_amdgcn_rcpf(beta);
         }
         if (tid == 0) {
             dz[j0 + jl] = dloc[jl] = col[jl];
             ez[j0 + jl] = eloc[jl] = beta;
             tz[j0 + jl] = tau;
         }
-        const float scal = tau != 0.f ? 1.f / (alpha - beta) : 0.f;
+        const float scal = tau != 0.f ? __builtin_amdgcn_rcpf(alpha - beta) : 0.f;
         if (tid < MMAX) u[tid] = tid < r0 ? 0.f : (tid == r0 ? 1.f : col[tid] * scal);
     };
     auto block_sum4 = [&](float x, float* slot) {      // sum over the threads < MMAX (whole waves), one barrier
@@ -531,7 +533,7 @@ __global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restr
     // this workgroup already owns a CU -- a separate launch would queue for wave slots behind the throughput kernels
     // of the other streams (rocprofv3, cfg-2: 0.17-0.49 ms inside a step for 0.05 ms of work).  The tridiagonal is
     // staged in LDS (the partials buffer is free now); entries of the first stage come from global memory.
-    if (rk.rank_out && z < rk.count && 2 * n <= WAVES * MMAX) {
+    if (rk.rank_out && z < rk.count && 2 * n <= 8 * MMAX) {
         __syncthreads();
         float* dl = &part[0][0];
         float* el = dl + n;
@@ -1160,11 +1162,14 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
         if (me != hipSuccess) return (int)me;
     }
     rk.status = err;
-    const bool fused_rank = tail && rk.rank_out && 2 * n <= 16 * TRI_TAIL_MAX;
+    const bool fused_rank = tail && rk.rank_out && 2 * n <= 8 * TRI_TAIL_MAX;
     if (tail) {
         MpRankOut in_tail = rk;
         if (!fused_rank) in_tail.rank_out = nullptr;
-        tridiag_tail_kernel<16, 16, 4><<<batch, 1024, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
+        if (g_tuning.tail == 2)      // experiment: 8 waves x 32 rows (cheaper barriers, two waves per SIMD)
+            tridiag_tail_kernel<8, 32, 4><<<batch, 512, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
+        else
+            tridiag_tail_kernel<16, 16, 4><<<batch, 1024, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
     }
     if (rk.rank_out && !fused_rank)
         tridiag_mp_rank_kernel<<<rk.count, 1024, 0, stream>>>(d, e, n, rk.factor, rk.cap, rk.rank_out, nullptr, rk.host_mirror ? err : nullptr, rk.host_mirror);
