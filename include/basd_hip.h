@@ -334,7 +334,9 @@ int basd_mix_grad_tokens(const float* r, const void* const* tok_ptrs, int dtype,
 int basd_token_weight_bwd(const float* gomega, const float* raw, int E, int B, int n_a, int n_s, const int* atap0,
                           const int* atap1, const float* alam, const int* arange0, const int* arange1,
                           const void* const* attn_ptrs, int dtype, int L, long sb, long sh, long sq, long sk, int H,
-                          int A, int has_cls, float* partial, hipStream_t stream);
+                          int A, int has_cls, float* partial,
+                          float* graw_out /* nullable: (E, B, n_a) d loss_b / d raw attention-grid weights */,
+                          hipStream_t stream);
 
 /* [masked cosine matrix ; identity] stacks (2 kmax x kmax, column-major) for the principal-angle SVD with
  * right singular vectors (backward of layer_selector.py:99). */

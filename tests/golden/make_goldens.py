@@ -236,6 +236,37 @@ def g_structure():
     save("structure.npz", **out)
 
 
+def g_checkpoint():
+    """Checkpoint interchange (reference trainer.py:84,94-123: accelerate stores the registered BASDLoss through
+    state_dict() / torch.save).  A reference-format state file with NON-default temperatures, the loss the reference
+    computes from it, and the reverse direction: the build's state_dict loaded into the reference module."""
+    shape, seed = TOY_VIT, 3
+    mod = _build_ref(shape, 0.01)
+    with torch.no_grad():
+        mod.layer_selector.log_temperatures += torch.linspace(-0.4, 0.5, shape.points)
+    torch.save(mod.state_dict(), os.path.join(HERE, "ref_basd_state.pth"))
+    inp = synth.make_inputs(shape, seed)
+    for v in inp.student.values():
+        v.requires_grad_(True)
+    with _SoftmaxTap() as tap:
+        loss = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
+    loss.backward()
+    out = {"loss": npf(loss), "mix_weights": npf(torch.stack([torch.softmax(a, dim=0) for a in tap.args])),
+           "grad_log_temperatures": npf(mod.layer_selector.log_temperatures.grad),
+           "log_temperatures": npf(mod.layer_selector.log_temperatures)}
+    # reverse: the build's module (constructed on CPU: no kernel needed) -> its state_dict -> the reference module
+    from basd_amd.losses import BASDLoss as OurLoss
+    torch.manual_seed(7)
+    ours = OurLoss(torch.nn.CrossEntropyLoss(), shape.d_s, shape.d_t, shape.depth, shape.n_s,
+                   config=SimpleNamespace(num_extraction_points=shape.points), teacher_has_cls_token=shape.has_cls)
+    ref2 = _build_ref(shape, 0.01, module_seed=123)
+    res = ref2.load_state_dict(ours.state_dict(), strict=True)
+    same = all(torch.equal(a, b) for a, b in zip(ref2.state_dict().values(), ours.state_dict().values()))
+    out["reverse_load_ok"] = np.int64(int(same and not res.missing_keys and not res.unexpected_keys))
+    out["ours_seed7_proj_t_abs_sum"] = np.float64(ours.layer_selector.proj_t.double().abs().sum())
+    save("checkpoint.npz", **out)
+
+
 def g_baseline_scalars(skip_large):
     """Scalar goldens at the BASELINE.json shapes (inputs regenerated from seed)."""
     out = {}
@@ -267,7 +298,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     steps = {
         "mp_rank": g_mp_rank, "subspace": g_subspace, "align": g_align, "relational": g_relational,
-        "full_small": g_full_small, "selector_outputs": g_selector_outputs, "structure": g_structure,
+        "full_small": g_full_small, "selector_outputs": g_selector_outputs, "structure": g_structure, "checkpoint": g_checkpoint,
         "baseline": lambda: g_baseline_scalars(args.skip_large),
     }
     for name, fn in steps.items():

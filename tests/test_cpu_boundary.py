@@ -2,6 +2,7 @@
 header declares, and the module mirrors the reference's constructor / state_dict contract."""
 import os
 import re
+import sys
 from types import SimpleNamespace
 
 import numpy as np
@@ -102,3 +103,31 @@ def test_interp_taps_match_oracle():
                 assert touching == list(range(touching[0], touching[-1] + 1))
             else:
                 assert int(r0[j]) >= int(r1[j])
+
+
+def test_reference_state_file_loads_on_cpu(golden):
+    """The reference-format state file (tests/golden/ref_basd_state.pth, written by the imported reference) has exactly
+    the build's state_dict keys, shapes and dtypes, and loads strictly (no kernels involved: runs without a GPU)."""
+    import os
+    from types import SimpleNamespace
+
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_goldens_shapes as S
+    from basd_amd.losses import BASDLoss
+    shape, _ = S.SMALL["vit"]
+    torch.manual_seed(7)
+    mod = BASDLoss(torch.nn.CrossEntropyLoss(), shape.d_s, shape.d_t, shape.depth, shape.n_s,
+                   config=SimpleNamespace(num_extraction_points=shape.points), teacher_has_cls_token=shape.has_cls)
+    g = golden("checkpoint.npz")
+    # same RNG consumption as the reference's constructor: the seed-7 projections match what make_goldens recorded
+    np.testing.assert_allclose(mod.layer_selector.proj_t.double().abs().sum().item(), g["ours_seed7_proj_t_abs_sum"], rtol=1e-12)
+    state = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ref_basd_state.pth"), map_location="cpu",
+                       weights_only=True)
+    own = mod.state_dict()
+    assert list(state.keys()) == list(own.keys())
+    for k in own:
+        assert state[k].shape == own[k].shape and state[k].dtype == own[k].dtype, k
+    mod.load_state_dict(state, strict=True)
+    np.testing.assert_array_equal(mod.layer_selector.log_temperatures.detach().numpy(), g["log_temperatures"])

@@ -79,6 +79,31 @@ def test_relational_golden(golden, tag):
     assert err < 1e-4, (tag, err)
 
 
+@pytest.mark.parametrize("tag", ["cls_same", "cls_interp", "nocls_uniform", "nocls_attn"])
+def test_relational_golden_teacher_side_gradients(golden, tag):
+    """geometric_relational_loss is differentiable w.r.t. the teacher tokens and the attention too
+    (relational.py:18-50): gradients against the reference's autograd on its own inputs."""
+    from basd_amd.losses import geometric_relational_loss
+    g = golden("relational.npz")
+    cls = bool(g[f"{tag}_meta"][6])
+    s = T(g[f"{tag}_s"]).to(DEV).requires_grad_(True)
+    t = T(g[f"{tag}_t"]).to(DEV).requires_grad_(True)
+    attn = T(g[f"{tag}_attn"]).to(DEV).requires_grad_(True)
+    loss = geometric_relational_loss(s, t, attn, has_cls_token=cls)
+    np.testing.assert_allclose(loss.item(), g[f"{tag}_loss"], rtol=1e-4)
+    gs, gt, ga = torch.autograd.grad(loss, [s, t, attn])
+    for got, name in ((gs, "grad_s"), (gt, "grad_t")):
+        ref = g[f"{tag}_{name}"]
+        err = np.linalg.norm(got.cpu().numpy() - ref) / np.linalg.norm(ref)
+        assert err < 2e-4, (tag, name, err)
+    assert ga.shape == attn.shape
+    np.testing.assert_allclose(ga.double().abs().sum().item(), g[f"{tag}_grad_attn_cls_row_sum"], rtol=2e-3)
+    if cls:                                                  # only the CLS row (minus the CLS column) receives gradient
+        mask = torch.ones_like(ga, dtype=torch.bool)
+        mask[:, :, 0, 1:] = False
+        assert ga[mask].abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("n_s,n_t,d_s,d_t,cls", [(196, 49, 384, 2048, False), (64, 64, 192, 256, True),
                                                   (36, 9, 64, 160, False), (64, 1, 192, 512, False),
                                                   (49, 64, 96, 128, True), (196, 256, 64, 96, False)])
@@ -385,3 +410,35 @@ def test_full_batch_properties(name, dtype):
     np.testing.assert_allclose(lb.mean(axis=1), comp["geo_layers"].cpu().numpy(), rtol=1e-5)
     if pc.sweeps is not None and int(pc.sweeps.max()) > 0:
         assert int(pc.sweeps.max()) < ops.MAX_SWEEPS
+
+
+def test_reference_checkpoint_round_trip_on_gpu(golden):
+    """Checkpoint interchange (reference trainer.py:84,94-123): a state file written by the REFERENCE module (with
+    trained, non-default temperatures) loads into the build's module on the GPU, and a step from it reproduces the
+    reference's loss, mixing weights and temperature gradient; the build's own state file loads back bit-equal."""
+    import io
+    g = golden("checkpoint.npz")
+    shape, seed = S.SMALL["vit"]
+    mod = _module(shape, 0.01)
+    state = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ref_basd_state.pth"), map_location=DEV,
+                       weights_only=True)
+    res = mod.load_state_dict(state, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    np.testing.assert_array_equal(mod.layer_selector.log_temperatures.detach().cpu().numpy(), g["log_temperatures"])
+    inp = synth.make_inputs(shape, seed, device=DEV)
+    leaves = {k: v.requires_grad_(True) for k, v in inp.student.items()}
+    loss = mod(inp.logits, inp.targets, leaves, inp.teacher, inp.attn)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    np.testing.assert_allclose(mod.last_components["mix"].cpu().numpy(), g["mix_weights"], rtol=2e-3, atol=1e-6)
+    loss.backward()
+    np.testing.assert_allclose(mod.layer_selector.log_temperatures.grad.cpu().numpy(), g["grad_log_temperatures"],
+                               rtol=3e-3, atol=1e-7)
+    # and back: save on the GPU, load into a fresh module (what accelerate's load_state does)
+    buf = io.BytesIO()
+    torch.save(mod.state_dict(), buf)
+    buf.seek(0)
+    fresh = _module(shape, 0.01)
+    fresh.load_state_dict(torch.load(buf, map_location=DEV, weights_only=True), strict=True)
+    for (ka, a), (kb, b) in zip(mod.state_dict().items(), fresh.state_dict().items()):
+        assert ka == kb and torch.equal(a, b)
+    assert int(g["reverse_load_ok"]) == 1       # recorded by make_goldens: the build's state_dict loads into the reference

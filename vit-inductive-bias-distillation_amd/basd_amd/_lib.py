@@ -65,7 +65,7 @@ SIGNATURES = {
     "basd_teacher_factor": [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "basd_mix_grad_tokens": [vp, vp, i32, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "basd_token_weight_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, i64, i32,
-                              i32, i32, vp, vp],
+                              i32, i32, vp, vp, vp],
     "basd_build_angle_stack": [vp, i32, vp, i32, vp, vp],
     "basd_grassmann_distance_bwd": [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp],
     "basd_eigvec_k2": [vp, vp, i32, i32, i32, vp, vp],

@@ -286,6 +286,49 @@ class _GrassmannDistance(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+class _RelationalAllInputs(torch.autograd.Function):
+    """(student, teacher, attn, has_cls) -> loss, differentiable w.r.t. ALL three tensors like the reference function
+    (relational.py:18-50).  The trainer never needs the teacher side (teacher outputs carry no grad, teacher.py:180);
+    the stand-alone function's contract does.  Teacher tokens arrive already on the student grid, so
+        d loss / d T = (2 / B) Kt T_c                       (the centring's adjoint vanishes: 1^T Kt T_c = 0)
+        d loss / d attn: d loss_b / d omega -> normalisation -> weight interpolation -> head / query mean."""
+
+    @staticmethod
+    def forward(ctx, student, teacher, attn, has_cls):
+        pc = ops.procrustes_forward([student], [teacher], [attn],
+                                    ops._device_consts((1.0,), torch.float32, student.device).view(1, 1), has_cls,
+                                    need_backward=True, need_mix_grad=True)
+        ctx.pc, ctx.has_cls = pc, has_cls
+        ctx.save_for_backward(student)
+        ctx.shapes = (teacher.shape, teacher.dtype, attn.shape, attn.dtype)
+        return pc.loss_b[0].mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (student,) = ctx.saved_tensors
+        pc = ctx.pc
+        t_shape, t_dtype, a_shape, a_dtype = ctx.shapes
+        B = t_shape[0]
+        gl = g.reshape(1).float()
+        kt, tnorm2 = ops.procrustes_teacher_factor(pc)
+        grads, gomega = ops.procrustes_student_grads([student], pc, gl, tnorm2)
+        _, r, g_raw = ops.procrustes_mix_grads(pc, kt, gomega, gl, want_inputs=True)
+        g_s = grads[0].to(student.dtype) if ctx.needs_input_grad[0] else None
+        g_t = g_a = None
+        if ctx.needs_input_grad[1]:
+            g_t = (r.view(t_shape) * (2.0 / B * gl)).to(t_dtype)
+        if ctx.needs_input_grad[2]:
+            _, H, A, _ = a_shape
+            g_a = torch.zeros(a_shape, device=g.device, dtype=torch.float32)
+            w = g_raw[0] * (gl / B)                                     # (B, n_a)
+            if ctx.has_cls:
+                g_a[:, :, 0, 1:] = (w / H).unsqueeze(1)                 # relational.py:24: CLS row, head mean
+            else:
+                g_a[:] = (w / (H * A)).view(B, 1, 1, -1)                # relational.py:27: head and query mean
+            g_a = g_a.to(a_dtype)
+        return g_s, g_t, g_a, None
+
+
 # --------------------------------------------------------------------------- #
 # reference src/losses/relational.py:5-50
 # --------------------------------------------------------------------------- #
@@ -297,11 +340,11 @@ def geometric_relational_loss(
     has_cls_token: bool,
 ) -> torch.Tensor:
     """Attention-weighted Procrustes loss between (B, N_s, D_s) student tokens and (B, N_s, D_t)
-    teacher tokens already on the student grid.  Differentiable w.r.t. the student tokens."""
+    teacher tokens already on the student grid.  Differentiable w.r.t. all three tensors, like the reference."""
     if teacher_tokens.shape[1] != student_tokens.shape[1]:
         raise RuntimeError("teacher_tokens must already be aligned to the student token count")
     if teacher_tokens.requires_grad or teacher_attn.requires_grad:
-        raise NotImplementedError("gradients w.r.t. teacher tokens / attention are not implemented yet")
+        return _RelationalAllInputs.apply(student_tokens, teacher_tokens, teacher_attn, bool(has_cls_token))
     mix = torch.ones((1, 1), device=student_tokens.device, dtype=torch.float32)
     return _ProcrustesLayers.apply(mix, bool(has_cls_token), False, None, [teacher_tokens], [teacher_attn], student_tokens)[0]
 

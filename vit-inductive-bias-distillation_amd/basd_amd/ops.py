@@ -653,8 +653,11 @@ def procrustes_teacher_factor(ctx: ProcrustesContext) -> tuple[torch.Tensor, tor
 
 
 def procrustes_mix_grads(ctx: ProcrustesContext, kt: torch.Tensor, gomega: torch.Tensor,
-                         grad_layers: torch.Tensor) -> torch.Tensor:
-    """d(sum_e grad_layers[e] * mean_b loss_b[e]) / d mix  -> (E, L)."""
+                         grad_layers: torch.Tensor, want_inputs: bool = False):
+    """d(sum_e grad_layers[e] * mean_b loss_b[e]) / d mix  -> (E, L).
+    ``want_inputs``: also return (R, g_raw): R = Kt T_c (E*B, n, d_t) with d loss_b / d T_c = 2 R, and g_raw (E, B, n_a)
+    = d loss_b / d (un-normalised attention-grid token weight) -- the gradients w.r.t. the teacher tokens / attention
+    of the stand-alone ``geometric_relational_loss`` are assembled from them."""
     mg = ctx.mixgrad
     E, B = ctx.loss_b.shape
     n, n_s, n_a = mg["n"], mg["n_s"], mg["n_a"]
@@ -679,11 +682,13 @@ def procrustes_mix_grads(ctx: ProcrustesContext, kt: torch.Tensor, gomega: torch
     sb, sh, sq, sk = attns[0].stride()
     H, A = attns[0].shape[1], attns[0].shape[2]
     part_att = torch.empty((E, B, L), device=dev, dtype=torch.float32)
+    g_raw = torch.empty((E, B, n_a), device=dev, dtype=torch.float32) if want_inputs else None
     _lib.call("basd_token_weight_bwd", gomega.data_ptr(), mg["raw"].data_ptr(), E, B, n_a, n_s, a0, a1, alam, ar0,
               ar1, mg["att_tab"].data_ptr(), _dtype_code(attns[0]), L, sb, sh, sq, sk, H, A, int(mg["has_cls"]),
-              part_att.data_ptr(), st)
+              part_att.data_ptr(), _ptr(g_raw), st)
     per_layer = (2.0 * part_tok + part_att).sum(dim=1) / B                 # (E, L): tiny torch glue
-    return per_layer * grad_layers.float().view(E, 1)
+    g_mix = per_layer * grad_layers.float().view(E, 1)
+    return (g_mix, r, g_raw) if want_inputs else g_mix
 
 
 # --------------------------------------------------------------------------- #

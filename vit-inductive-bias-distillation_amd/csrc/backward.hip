@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(256) token_weight_bwd_kernel(
     const float* __restrict__ gomega, const float* __restrict__ raw, int n_a, int n_s,
     const int* __restrict__ atap0, const int* __restrict__ atap1, const float* __restrict__ alam,
     const int* __restrict__ arange0, const int* __restrict__ arange1, const void* const* __restrict__ attn_ptrs,
-    int L, long sb, long sh, long sq, long sk, int H, int A, int has_cls, float* __restrict__ partial) {
+    int L, long sb, long sh, long sq, long sk, int H, int A, int has_cls, float* __restrict__ partial,
+    float* __restrict__ graw_out) {
     extern __shared__ float sm[];
     float* gv = sm;             // n_s
     float* graw = sm + n_s;     // n_a
@@ -160,6 +161,7 @@ __global__ void __launch_bounds__(256) token_weight_bwd_kernel(
             acc = gv[j];
         }
         graw[j] = acc;
+        if (graw_out) graw_out[((long)e * B + b) * n_a + j] = acc;     // d loss_b / d (raw attention-grid weight)
     }
     __syncthreads();
     for (int l = 0; l < L; ++l) {
@@ -335,15 +337,15 @@ int basd_mix_grad_tokens(const float* r, const void* const* tok_ptrs, int dtype,
 int basd_token_weight_bwd(const float* gomega, const float* raw, int E, int B, int n_a, int n_s, const int* atap0,
                           const int* atap1, const float* alam, const int* arange0, const int* arange1,
                           const void* const* attn_ptrs, int dtype, int L, long sb, long sh, long sq, long sk, int H,
-                          int A, int has_cls, float* partial, hipStream_t stream) {
+                          int A, int has_cls, float* partial, float* graw_out, hipStream_t stream) {
     BASD_CHECK_ARG(gomega && raw && attn_ptrs && partial && E > 0 && B > 0 && n_a > 0 && n_s > 0 && L > 0);
     BASD_CHECK_ARG((n_a == n_s) == (atap0 == nullptr));
     const size_t lds = sizeof(float) * (size_t)(n_s + n_a);
     const dim3 grid(B, E);
     if (dtype == BASD_DTYPE_F32)
-        token_weight_bwd_kernel<float><<<grid, 256, lds, stream>>>(gomega, raw, n_a, n_s, atap0, atap1, alam, arange0, arange1, attn_ptrs, L, sb, sh, sq, sk, H, A, has_cls, partial);
+        token_weight_bwd_kernel<float><<<grid, 256, lds, stream>>>(gomega, raw, n_a, n_s, atap0, atap1, alam, arange0, arange1, attn_ptrs, L, sb, sh, sq, sk, H, A, has_cls, partial, graw_out);
     else if (dtype == BASD_DTYPE_BF16)
-        token_weight_bwd_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>(gomega, raw, n_a, n_s, atap0, atap1, alam, arange0, arange1, attn_ptrs, L, sb, sh, sq, sk, H, A, has_cls, partial);
+        token_weight_bwd_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>(gomega, raw, n_a, n_s, atap0, atap1, alam, arange0, arange1, attn_ptrs, L, sb, sh, sq, sk, H, A, has_cls, partial, graw_out);
     else
         return BASD_EINVAL;
     BASD_RETURN_LAST();
