@@ -122,7 +122,8 @@ def test_estimate_intrinsic_dim_on_the_library():
     model.add_module("stage", _Last())
     teacher = SimpleNamespace(model=model, layer_paths=["stage"], feature_format="token", has_cls_token=False)
     got = capture.estimate_intrinsic_dim(teacher, torch.zeros(1, device=dev))
-    assert got == O.mp_rank(feats) == 40
+    ref = O.mp_rank(feats)
+    assert got == ref and 40 <= ref < 64          # the planted rank plus the noise eigenvalues past the MP edge
 
 
 @pytest.mark.gpu
