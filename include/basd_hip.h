@@ -102,8 +102,9 @@ int basd_jacobi_workspace_ints(int batch, int max_sweeps);
  * (:36, :92), torch.linalg.svdvals (:99) and torch.linalg.matrix_norm(ord="nuc") (relational.py:48).
  * n_arr (nullable): per-matrix order for square problems.  flags: basd_jacobi_workspace_ints() ints.
  * tol_cos: stop when every pair has |cos| <= tol_cos over a full sweep (<= 0: eps * sqrt(rows_dot)). */
-/* Test / tuning hook: lanes per column pair of the LDS-resident solver; 0 or 16 = one DPP row of 16 lanes (default),
- * 4 = one quad (stacked matrices only; same results, measured no faster). */
+/* Test / tuning hook: lanes per column pair of the LDS-resident solver; 0 = automatic (batches >= 256 of stacked
+ * matrices: 4 lanes for n >= 40, 8 for n >= 16 -- fewer instruction issues per matrix round; else one DPP row of 16),
+ * 4 / 8 / 16 = forced where the shape allows. */
 int basd_jacobi_tuning(int lanes_per_pair);
 
 int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot, int n, int batch,
@@ -138,6 +139,7 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
  * ranks and then the factorisation's 8 status words. */
 int basd_tridiag_ranked(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
                         void* work, int rank_count, double factor, int cap, int* rank_out, int* host_mirror,
+                        void* mid_event /* nullable hipEvent_t: recorded behind the multi-workgroup stage */,
                         hipStream_t stream);
 
 /* Test / tuning hook for basd_tridiag (the only process-wide setting of the library; its defaults come from the
@@ -280,7 +282,7 @@ int basd_student_grad_multi(const void* const* x_ptrs, int dtype, long sb, long 
  * front of the caller's stream).  All fields are 8 bytes wide; pointers are device memory except student_host_ptrs.
  *   G = 1: the teacher side is shared by all layers (one teacher layer: mixing weights exactly 1), else G = E.
  *   n = min(n_s, n_t): the core grid.  Arrays: omega (G,B,n_s), omega_t (G,B,n), raw (G,B,n_a) nullable,
- *   mu_t (G,B,d_t), tc (G,B,n,d_t), mu_s (E,B,d_s), tr_part (E,B,ceil(d_s/64)), tr_s/tr_t/nuc/loss_b (E,B),
+ *   mu_t (G,B,d_t), tc (G,B,n,d_t), mu_s (E,B,d_s), tr_part (E,B,ceil(d_s/32)), tr_s/tr_t/nuc/loss_b (E,B),
  *   a_prime (E,B,n,d_s), g_all/l_all ((E+G)B,n,n) fp64, W (EB,n,2n), sigma (EB,n),
  *   jflags basd_jacobi_workspace_ints(EB, max_sweeps) ints, sweeps (EB) ints nullable, k_prime (EB,n,n) nullable,
  *   h (EB,n,d_s) + dx (E,B,n_s,d_s) + grad_layers (E): only for the gradients. */
@@ -313,6 +315,11 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* args, hipStream_t st
  * such partitions and this library's throughput kernels on the complement, so that neither slows the other down. */
 int basd_stream_create_masked(int cu_lo, int cu_hi, int invert, hipStream_t* out);
 int basd_stream_destroy(hipStream_t stream);
+
+/* Events to order two streams from inside a library call (basd_tridiag_ranked's mid_event): opaque hipEvent_t handles. */
+int basd_event_create(void** out);
+int basd_event_destroy(void* event);
+int basd_stream_wait_event(hipStream_t stream, void* event);
 
 /* ---- multi-layer teachers only: gradients through the mixing weights and the principal angles ------ */
 

@@ -107,13 +107,14 @@ def test_centered_grams_multi(dev, B, N, D, dtype):
 
 @pytest.mark.parametrize("n,rows_dot,rows_tot,batch", [
     (49, 49, 98, 5), (50, 50, 100, 5), (7, 7, 7, 5), (96, 96, 192, 5), (130, 130, 130, 5),
-    # negative batch: the 4-lanes-per-pair kernel shape (basd_jacobi_tuning)
-    (49, 49, 98, -30), (31, 31, 62, -26), (64, 64, 128, -8), (9, 9, 18, -6), (24, 30, 61, -7)])
+    # batch < 0: the 4-lanes-per-pair kernel shape, batch > 1000: the 8-lanes one (basd_jacobi_tuning)
+    (49, 49, 98, -30), (31, 31, 62, -26), (64, 64, 128, -8), (9, 9, 18, -6), (24, 30, 61, -7),
+    (49, 49, 98, 1030), (31, 31, 62, 1026), (64, 64, 128, 1008), (9, 9, 18, 1006), (24, 30, 61, 1007)])
 def test_jacobi_lds_invariants(dev, n, rows_dot, rows_tot, batch):
     from basd_amd import ops, _lib
     g = torch.Generator().manual_seed(n)
-    _lib.call("basd_jacobi_tuning", 4 if batch < 0 else 0)
-    batch = abs(batch)
+    _lib.call("basd_jacobi_tuning", 4 if batch < 0 else (8 if batch > 1000 else 0))
+    batch = abs(batch) % 1000
     w0 = torch.randn(batch, n, rows_tot, generator=g)
     w0[:, :, :rows_dot] *= torch.logspace(0, -3, n).view(1, n, 1)       # spread the spectrum
     W = w0.clone().to(dev)

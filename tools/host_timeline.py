@@ -42,6 +42,9 @@ for _ in range(N):
         acc[label] = acc.get(label, 0.0) + (t - t0)
 torch.cuda.synchronize()
 print("ms/step %.3f" % ((time.perf_counter() - t_all) / N * 1e3))
+if ops.CHAIN_EVENTS:
+    ch = sorted(a.elapsed_time(b) for a, b in ops.CHAIN_EVENTS)
+    print("teacher chain on the GPU (start -> ranks): median %.3f ms, min %.3f, max %.3f" % (ch[len(ch) // 2], ch[0], ch[-1]))
 prev = 0.0
 for label, s in acc.items():
     print("%-20s %8.1f us   (+%.1f)" % (label, s / N * 1e6, s / N * 1e6 - prev))

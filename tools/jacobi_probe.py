@@ -5,12 +5,12 @@ sys.path.insert(0, os.path.join(ROOT, "vit-inductive-bias-distillation_amd"))
 import torch
 from basd_amd import ops, _lib
 dev = "cuda:0"
-for n, rd, rt, batch, graded in [(49, 49, 98, 300, True), (49, 49, 98, 1024, False), (49, 49, 98, 1024, True)]:
+for n, rd, rt, batch, graded in [(49, 49, 98, 1024, False), (49, 49, 98, 1024, True), (36, 36, 72, 512, False)]:
     g = torch.Generator().manual_seed(n)
     w0 = torch.randn(batch, n, rt, generator=g)
     if graded:
         w0[:, :, :rd] *= torch.logspace(0, -3, n).view(1, n, 1)
-    for lanes in (16, 4):
+    for lanes in (16, 8, 4):
         _lib.call("basd_jacobi_tuning", lanes)
         W = w0.clone().to(dev)
         torch.cuda.synchronize()

@@ -33,7 +33,10 @@ SIGNATURES = {
     "basd_tridiag_workspace_bytes": [i32, i32],
     "basd_tridiag_tuning": [i32, i32, i32, i32, i32, i32],
     "basd_tridiag": [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp],
-    "basd_tridiag_ranked": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp],
+    "basd_tridiag_ranked": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp, vp],
+    "basd_event_create": [vp],
+    "basd_event_destroy": [vp],
+    "basd_stream_wait_event": [vp, vp],
     "basd_tridiag_eigenvalues": [vp, vp, i32, i32, vp, vp],
     "basd_tridiag_apply_q": [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp],
     "basd_tridiag_shifted_solve": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],

@@ -358,6 +358,7 @@ class GrassmannianLayerSelector(nn.Module):
         self.student_dim = student_dim
         self._subspace_ranks: dict[int, int] = {}
         self._pending_tail = None          # deferred rank read-back + selector tail of the latest forward
+        self.gate_student_chain = os.environ.get("BASD_STUDENT_GATE", "1") != "0"
 
         # Same global-RNG consumption order as the reference (proj_s, then proj_t), on CPU.
         proj_s = torch.empty(student_dim, student_dim)
@@ -472,37 +473,54 @@ class GrassmannianLayerSelector(nn.Module):
         st = dict(E=E, L=L, tri=tri, stud_jacobi=stud_jacobi, student_stream=student_stream)
         eig_t, eig_s = eig_streams if (eig_streams is not None and tri) else (None, None)
 
-        # ---- student side: centred Grams -> eigen-solve ----
         cur = torch.cuda.current_stream()
         projected = None
+        chain_t0 = None
+        if ops.HOST_TRACE is not None:             # diagnostics (tools/host_timeline.py): GPU time of the teacher chain
+            chain_t0 = torch.cuda.Event(enable_timing=True)
+            chain_t0.record()
         if student_stream is not None:
             student_stream.wait_stream(cur)
             # two chains: give the teacher stream its first (large) launch before the host queues the
             # student chain, so both start together
             projected = self._teacher_projections(teachers)
-        with torch.cuda.stream(student_stream if student_stream is not None else cur):
-            # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
-            # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
-            xs = ops._check_common_layout([ops.as_supported(x) for x in students], "student token tensors")
-            s_stack, means = ops.centered_grams(xs)
-            st["means"] = means
-            if stud_jacobi:
-                st["s_stack"], st["s_colnorm"] = s_stack, ops.jacobi_onesided(s_stack, d_s)
-            else:
-                if eig_s is not None:
-                    eig_s.wait_stream(torch.cuda.current_stream())
-                    s_stack.record_stream(eig_s)
-                with torch.cuda.stream(eig_s if eig_s is not None else torch.cuda.current_stream()):
-                    s_ts = ops.tridiagonalise(s_stack)
-                    if student_stream is not None:
-                        # status word of this factorisation: read by the host one step later (it never waits for
-                        # the student chain)
-                        st["student_status"] = self._queue_readback([s_ts.err], "student")
-                    elif eig_s is None:
-                        # same stream as the teacher chain that follows: this copy is complete when the rank event is
-                        st["student_status_now"] = self._queue_readback([s_ts.err], "student")
-                    ops.tridiag_spectrum(s_ts)
-                st["s_ts"] = s_ts
+
+        def student_chain(gate=None):
+            """centred Grams -> eigen-solve of the E student layers; ``gate``: event the chain waits for first"""
+            with torch.cuda.stream(student_stream if student_stream is not None else cur):
+                if gate is not None:
+                    ops.stream_wait_event(torch.cuda.current_stream(), gate)
+                # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
+                # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
+                xs = ops._check_common_layout([ops.as_supported(x) for x in students], "student token tensors")
+                s_stack, means = ops.centered_grams(xs)
+                st["means"] = means
+                if stud_jacobi:
+                    st["s_stack"], st["s_colnorm"] = s_stack, ops.jacobi_onesided(s_stack, d_s)
+                else:
+                    if eig_s is not None:
+                        eig_s.wait_stream(torch.cuda.current_stream())
+                        s_stack.record_stream(eig_s)
+                    with torch.cuda.stream(eig_s if eig_s is not None else torch.cuda.current_stream()):
+                        s_ts = ops.tridiagonalise(s_stack)
+                        if student_stream is not None:
+                            # status word of this factorisation: read by the host one step later (it never waits
+                            # for the student chain)
+                            st["student_status"] = self._queue_readback([s_ts.err], "student")
+                        elif eig_s is None:
+                            # same stream as the teacher chain that follows: complete when the rank event is
+                            st["student_status_now"] = self._queue_readback([s_ts.err], "student")
+                        ops.tridiag_spectrum(s_ts)
+                    st["s_ts"] = s_ts
+
+        # Two chains: the student chain is not on the path the host waits for, and its Gram launch (the largest MFMA
+        # launch of the step) next to the teacher's Grams / multi-workgroup tridiagonalisation stage costs the teacher
+        # chain ~1 ms (rocprofv3: teacher Grams 0.46 ms instead of 0.06, shared stage 0.72 instead of 0.48).  So it is
+        # queued BEHIND the teacher chain and gated on an event recorded after that stage -- from there on the teacher
+        # factorisation sits in one CU per matrix and no longer cares.
+        gated = student_stream is not None and tri and self.gate_student_chain
+        if not gated:
+            student_chain()
 
         # ---- teacher side: projection, Grams, eigen-solve, MP ranks ----
         g_u, g_c, M, t_stack = self._teacher_grams(teachers, projected)
@@ -521,14 +539,25 @@ class GrassmannianLayerSelector(nn.Module):
             with torch.cuda.stream(eig_t if eig_t is not None else cur):
                 # ranks straight out of the factorisation's last kernel                          (:16-19, :74)
                 pin = self._pinned_ints("teacher", L + 8)
-                ts = ops.tridiagonalise(t_stack, mp_rank=(M, d_s, d_s - 1, L, pin))
+                gate = None
+                if gated:
+                    if getattr(self, "_gate_event", None) is None:
+                        self._gate_event = ops.new_event()
+                    gate = self._gate_event
+                ts = ops.tridiagonalise(t_stack, mp_rank=(M, d_s, d_s - 1, L, pin, gate))
                 st["t_ts"] = ts
                 st["ranks_dev"] = ts.ranks
-                ready = torch.cuda.Event()
+                ready = torch.cuda.Event(enable_timing=chain_t0 is not None)
                 ready.record()
                 st["rank_ready"] = (pin, ready)
+                if chain_t0 is not None:
+                    ops.CHAIN_EVENTS.append((chain_t0, ready))
                 ops.tridiag_spectrum(ts, first=o_c, count=L)
+            if gated:
+                student_chain(gate)
             return st
+        if gated:
+            student_chain()
         if tri:
             ts = ops.tridiag_eigenvalues(t_stack)
             st["t_ts"] = ts

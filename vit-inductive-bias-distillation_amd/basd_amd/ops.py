@@ -57,6 +57,7 @@ CONSUMER_STREAM = None
 
 # Host-side timeline of a step (tools/host_timeline.py): list of (label, perf_counter) when switched on.
 HOST_TRACE: list | None = None
+CHAIN_EVENTS: list = []          # (start, rank-ready) timing events of the teacher chain while HOST_TRACE is on
 
 
 def trace(label: str) -> None:
@@ -249,7 +250,7 @@ class TridiagState:
 def tridiagonalise(G: torch.Tensor, mp_rank: tuple | None = None) -> TridiagState:
     """G (batch, n, n) symmetric, DESTROYED.  Queues the Householder tridiagonalisation; ``vals`` is allocated but
     not filled (``tridiag_spectrum``).  No host sync.
-    ``mp_rank`` = (M, D, cap, count, host_mirror | None): also the Marchenko-Pastur ranks of the first ``count``
+    ``mp_rank`` = (M, D, cap, count, host_mirror | None[, mid_event handle | None]): also the Marchenko-Pastur ranks of the first ``count``
     matrices (``ts.ranks``, int32 on device), from the kernel that finishes the factorisation; ``host_mirror``: pinned
     int32 host tensor of count + 8 elements filled with the ranks and the status words (read it after an event
     recorded behind this call)."""
@@ -266,14 +267,27 @@ def tridiagonalise(G: torch.Tensor, mp_rank: tuple | None = None) -> TridiagStat
         _lib.call("basd_tridiag", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
                   vh.data_ptr(), work.data_ptr(), _stream())
     else:
-        M, D, cap, count, mirror = mp_rank
+        M, D, cap, count, mirror, mid_event = (tuple(mp_rank) + (None,))[:6]
         factor = (1 + (D / M) ** 0.5) ** 2          # float64 on the host, as reference layer_selector.py:11,18
         ranks = torch.empty((count,), device=G.device, dtype=torch.int32)
         if mirror is not None:
             assert mirror.is_pinned() and mirror.dtype == torch.int32 and mirror.numel() == count + 8
         _lib.call("basd_tridiag_ranked", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
-                  vh.data_ptr(), work.data_ptr(), count, factor, cap, ranks.data_ptr(), _ptr(mirror), _stream())
+                  vh.data_ptr(), work.data_ptr(), count, factor, cap, ranks.data_ptr(), _ptr(mirror), mid_event,
+                  _stream())
     return TridiagState(d, e, tau, vh, vals, work[-32:].view(torch.int32), ranks)
+
+
+def new_event() -> int:
+    """A raw hipEvent_t handle (basd_event_create) for ordering streams from inside library calls."""
+    import ctypes
+    h = ctypes.c_void_p()
+    _lib.call("basd_event_create", ctypes.byref(h))
+    return h.value
+
+
+def stream_wait_event(stream: "torch.cuda.Stream", event: int) -> None:
+    _lib.call("basd_stream_wait_event", stream.cuda_stream, event)
 
 
 def tridiag_spectrum(ts: TridiagState, first: int = 0, count: int | None = None) -> torch.Tensor:
@@ -537,7 +551,7 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     shared = L == 1            # softmax over one layer is exactly 1: the teacher side is identical for all e
     G = 1 if shared else E
     f32 = dict(device=dev, dtype=torch.float32)
-    slabs = (d_s + 63) // 64
+    slabs = (d_s + 31) // 32
     EB, GB = E * B, G * B
     need_bwd = need_backward or grad_layers is not None
     # kept for the backward / returned

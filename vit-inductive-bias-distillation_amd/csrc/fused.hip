@@ -32,11 +32,12 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
     }
     // student side: all layers in one launch where the vectorised kernel applies
     const long om_stride = G == 1 ? 0 : (long)B * n_s;
-    const int slabs = (d_s + 63) / 64;
+    int slabs = (d_s + 31) / 32;          // partial traces per sample: 32-feature slabs (multi) or 64 (per layer)
     rc = basd_student_project_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s,
                                     (int)a->s_aligned, a->omega, om_stride, a->tap0, a->tap1, a->lam, a->range0,
                                     a->range1, a->mu_s, a->tr_part, a->a_prime, st);
     if (rc == BASD_EUNSUPPORTED) {
+        slabs = (d_s + 63) / 64;
         for (int e = 0; e < E; ++e)
             BASD_TRY(basd_student_project(a->student_host_ptrs[e], (int)a->s_dtype, a->s_sb, a->s_sn, B, n_s, n, d_s,
                                           a->omega + e * om_stride, a->tap0, a->tap1, a->lam, a->range0, a->range1,
@@ -95,6 +96,22 @@ int basd_stream_create_masked(int cu_lo, int cu_hi, int invert, hipStream_t* out
         }
     }
     hipError_t e = hipExtStreamCreateWithCUMask(out, 8, mask);
+    return e == hipSuccess ? BASD_OK : (int)e;
+}
+
+// Events for ordering two streams from inside a library call (see basd_tridiag_ranked's mid_event).
+int basd_event_create(void** out) {
+    BASD_CHECK_ARG(out);
+    hipError_t e = hipEventCreateWithFlags((hipEvent_t*)out, hipEventDisableTiming);
+    return e == hipSuccess ? BASD_OK : (int)e;
+}
+int basd_event_destroy(void* ev) {
+    hipError_t e = hipEventDestroy((hipEvent_t)ev);
+    return e == hipSuccess ? BASD_OK : (int)e;
+}
+int basd_stream_wait_event(hipStream_t stream, void* ev) {
+    BASD_CHECK_ARG(ev);
+    hipError_t e = hipStreamWaitEvent(stream, (hipEvent_t)ev, 0);
     return e == hipSuccess ? BASD_OK : (int)e;
 }
 

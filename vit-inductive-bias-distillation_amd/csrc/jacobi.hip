@@ -67,10 +67,11 @@ __device__ __forceinline__ Rot make_rotation(float alpha, float beta, float gamm
 
 template <int LPP>
 __device__ __forceinline__ float pair_allsum(float x) {
-    static_assert(LPP == 4 || LPP == 16 || LPP == 64, "a pair is owned by one quad, one DPP row or one wave");
-    if constexpr (LPP == 4) {
+    static_assert(LPP == 4 || LPP == 8 || LPP == 16 || LPP == 64, "a pair is owned by a quad, half a DPP row, a row or a wave");
+    if constexpr (LPP == 4 || LPP == 8) {
         x += dpp_get<0xB1>(x);    // quad_perm [1,0,3,2]
         x += dpp_get<0x4E>(x);    // quad_perm [2,3,0,1]
+        if constexpr (LPP == 8) x += dpp_get<0x141>(x);   // row_half_mirror
         return x;
     } else {
         return LPP == 16 ? row16_allsum(x) : wave64_allsum(x);
@@ -162,7 +163,13 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
                                                            int rows_tot, int n_fixed, const int* __restrict__ n_arr,
                                                            int max_sweeps, float tol, float* __restrict__ colnorm,
                                                            int colnorm_stride, int* __restrict__ sweeps_out) {
-    constexpr int LD = LPP * EPL + 2;   // even: 8-byte aligned columns for the paired accesses
+    // Column stride.  16 lanes per pair: + 2 (even: 8-byte aligned columns; PMC: no bank conflicts).  4 lanes per pair: a
+    // half-wave's ds_read_b64 touches 8 different columns, 8 banks each; with the stride 8 x odd the 8 consecutive
+    // columns of a round-robin round tile the 64 banks exactly (PMC with + 2: 40 % of the LDS cycles were conflicts).
+    // (8 lanes per pair: 4 columns of 16 banks per half-wave, stride 16 x odd.)
+    constexpr int LD = LPP * EPL + (LPP == 4 ? 8 : LPP == 8 ? 16 : 2);
+    static_assert(LPP != 4 || ((LPP * EPL / 8) % 2 == 0), "stride must come out as 8 x odd");
+    static_assert(LPP != 8 || ((LPP * EPL / 16) % 2 == 0), "stride must come out as 16 x odd");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m = blockIdx.x;
     int n = n_arr ? n_arr[m] : n_fixed;
@@ -441,12 +448,11 @@ extern "C" {
 
 int basd_jacobi_workspace_ints(int batch, int max_sweeps) { return 2 * batch * max_sweeps; }
 
-// Test / tuning hook: lanes per column pair of the LDS-resident solver -- 0 / 16 = one DPP row per pair (default),
-// 4 = one quad per pair for stacked matrices (measured on MI355X, 1024 x (98 x 49): 0.84 ms against 0.87 -- the fewer
-// instruction issues are paid back in per-wave latency, so it is not selected automatically).  Process-wide.
+// Test / tuning hook: lanes per column pair of the LDS-resident solver -- 0 = automatic, 4 / 8 / 16 = forced where the
+// shape allows (4 and 8: stacked matrices only).  Process-wide.
 static int g_jacobi_lanes = 0;
 int basd_jacobi_tuning(int lanes_per_pair) {
-    if (lanes_per_pair != 0 && lanes_per_pair != 4 && lanes_per_pair != 16) return BASD_EINVAL;
+    if (lanes_per_pair != 0 && lanes_per_pair != 4 && lanes_per_pair != 8 && lanes_per_pair != 16) return BASD_EINVAL;
     g_jacobi_lanes = lanes_per_pair;
     return BASD_OK;
 }
@@ -473,15 +479,48 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
     const int epl = stacked ? 2 * half : dot16;
     BASD_CHECK_ARG(!(stacked && n_arr));
 
+    // ---- LDS-resident, 8 lanes per column pair (stacked matrices) ----
+    // automatic choice for large batches of stacked matrices (measured on MI355X, 1024 x (98 x 49): 0.87 ms with 16 lanes
+    // per pair, 0.80 with 8, 0.70 with 4; 512 x (72 x 36): 0.45 / 0.36 / 0.41)
+    int lanes = g_jacobi_lanes;
+    if (lanes == 0 && stacked && batch >= 256) lanes = n_even >= 40 ? 4 : (n_even >= 16 ? 8 : 16);
+    if (stacked && n_even >= 8 && lanes == 8) {
+        const int dot16 = (rows_dot + 15) / 16, ride16 = (rows_tot - rows_dot + 15) / 16;
+        const int half16 = dot16 > ride16 ? dot16 : ride16;       // 16-row chunks per half; DOT = 2 * half16
+        const int d8 = 2 * half16;
+        const size_t lds8 = (size_t)n_even * (8 * 2 * d8 + 16 + 2) * sizeof(float);
+        if (d8 <= 8 && lds8 <= BASD_JACOBI_LDS_LIMIT) {
+            int threads = (((n_even / 2) * 8 + 63) / 64) * 64;
+            if (threads > 1024) threads = 1024;
+#define LAUNCH_LDS8(D)                                                                                               \
+    do {                                                                                                             \
+        if (lds8 > 48 * 1024)                                                                                        \
+            (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<2 * (D), D, 8>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BASD_JACOBI_LDS_LIMIT);            \
+        jacobi_lds_kernel<2 * (D), D, 8><<<batch, threads, lds8, stream>>>(W, batch_stride, rows_dot, rows_tot, n,   \
+                                                                           n_arr, max_sweeps, tol, colnorm,          \
+                                                                           colnorm_stride, sweeps_out);              \
+    } while (0)
+            switch (d8) {
+                case 2: LAUNCH_LDS8(2); break;
+                case 4: LAUNCH_LDS8(4); break;
+                case 6: LAUNCH_LDS8(6); break;
+                default: LAUNCH_LDS8(8); break;
+            }
+#undef LAUNCH_LDS8
+            BASD_RETURN_LAST();
+        }
+    }
+
     // ---- LDS-resident, throughput shape: large batches of small stacked matrices, 4 lanes per column pair ----
-    if (stacked && n_even >= 8 && g_jacobi_lanes == 4) {
+    if (stacked && n_even >= 8 && lanes == 4) {
         const int dot8 = (rows_dot + 7) / 8, ride8 = (rows_tot - rows_dot + 7) / 8;
         const int half8 = dot8 > ride8 ? dot8 : ride8;            // 8-row chunks per half; DOT = 2 * half8 elements / lane
         static const int q_dot[] = {8, 12, 14, 16};
         int d4 = 0;
         for (int dq : q_dot)
             if (dq >= 2 * half8) { d4 = dq; break; }
-        const size_t lds4 = (size_t)n_even * (4 * 2 * d4 + 4) * sizeof(float);
+        const size_t lds4 = (size_t)n_even * (4 * 2 * d4 + 8 + 2) * sizeof(float);
         if (d4 && lds4 <= BASD_JACOBI_LDS_LIMIT) {
             int threads = (((n_even / 2) * 4 + 63) / 64) * 64;
             if (threads > 1024) threads = 1024;

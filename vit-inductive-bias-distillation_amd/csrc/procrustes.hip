@@ -247,12 +247,15 @@ __global__ void __launch_bounds__(256) student_project_lds_kernel(const T* __res
     }
 }
 
-// All E extraction layers in ONE launch, 16-byte LDS accesses.  grid = (ceil(D/64), B, E), block = 256 =
-// 16 feature quads x 16 row groups.  The (n_s x 64) slab is staged once by coalesced 16-byte loads (256 contiguous
-// bytes per row: a wave's ds_write_b128 / ds_read_b128 of 16 lanes per row are conflict-free by construction);
-// thread (fq, rg) then owns features 4 fq .. 4 fq + 3 and rows rg, rg + 16, ...: every sweep reads float4s, a sixth
-// of the LDS instructions of the 4-byte version above (which was bound by LDS issue at 0.9 TB/s of HBM traffic).
+// All E extraction layers in ONE launch, 16-byte LDS accesses.  grid = (ceil(D/32), B, E), block = 256 =
+// 8 feature quads x 32 row groups.  The (n_s x 32) slab (128-byte rows, contiguous in LDS) is staged once by
+// coalesced 16-byte loads; 16 consecutive lanes cover 256 contiguous LDS bytes, so the ds_write_b128 / ds_read_b128
+// are conflict-free by construction.  Thread (fq, rg) owns features 4 fq .. 4 fq + 3 and rows rg, rg + 32, ...: every
+// sweep reads float4s (a sixth of the LDS instructions of the 4-byte version above, which ran at 0.9 TB/s of HBM
+// traffic, bound by LDS issue), and the interpolation coefficients sit in LDS too (they used to be three dependent
+// global loads per row of the projection loop).  27 KB of LDS per workgroup at n_s = 196: five workgroups per CU.
 // x_ptrs: device table of E base pointers (same strides); omega + e * omega_e_stride; outputs are (E, B, ...).
+constexpr int SP_W = 32;          // slab width in features
 template <typename T>
 __global__ void __launch_bounds__(256) student_project_v4_kernel(const void* const* __restrict__ x_ptrs, long sb,
                                                                  long sn, int n_s, int n_t, int D,
@@ -265,36 +268,50 @@ __global__ void __launch_bounds__(256) student_project_v4_kernel(const void* con
                                                                  float* __restrict__ mu_out,
                                                                  float* __restrict__ tr_part, float* __restrict__ Ap) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* xs = sm;                      // n_s x 64 slab, row-major
-    float* w = sm + (long)n_s * 64;      // n_s
-    __shared__ __attribute__((aligned(16))) float red[16][64];
-    __shared__ __attribute__((aligned(16))) float mu[64];
+    float* xs = sm;                        // n_s x 32 slab, row-major
+    float* w = sm + (long)n_s * SP_W;      // n_s: token weights
+    float* c0 = w + n_s;                   // n_s: weight of row n towards teacher token t0[n]   ((1 - lam) w)
+    float* c1 = c0 + n_s;                  // n_s: ... towards t1[n]                               (lam w)
+    int* t0 = (int*)(c1 + n_s);            // n_s
+    int* t1 = t0 + n_s;                    // n_s
+    __shared__ __attribute__((aligned(16))) float red[32][SP_W];
+    __shared__ __attribute__((aligned(16))) float mu[SP_W];
     __shared__ float scratch[32];
-    const int b = blockIdx.y, e = blockIdx.z, B = gridDim.y, d0 = blockIdx.x * 64, tid = threadIdx.x;
-    const int fq = tid & 15, rg = tid >> 4, c4 = 4 * fq;
-    const bool live = d0 + c4 < D;       // D % 4 == 0: the quad is inside or outside
+    const int b = blockIdx.y, e = blockIdx.z, B = gridDim.y, d0 = blockIdx.x * SP_W, tid = threadIdx.x;
+    const int fq = tid & 7, rg = tid >> 3, c4 = 4 * fq;
+    const bool live = d0 + c4 < D;         // D % 4 == 0: the quad is inside or outside
     const T* Xb = (const T*)x_ptrs[e] + (long)b * sb + d0;
     const float* om = omega + (long)e * omega_e_stride + (long)b * n_s;
-    for (int n = tid; n < n_s; n += 256) w[n] = om[n];
-    for (int n = rg; n < n_s; n += 16) {
+    for (int n = tid; n < n_s; n += 256) {
+        const float wn = om[n];
+        w[n] = wn;
+        if (tap0) {
+            const float l1 = lam[n];
+            c0[n] = (1.f - l1) * wn;
+            c1[n] = l1 * wn;
+            t0[n] = tap0[n];
+            t1[n] = tap1[n];
+        }
+    }
+    for (int n = rg; n < n_s; n += 32) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live) v = ld4f(Xb + (long)n * sn + c4);
-        *(float4*)(xs + n * 64 + c4) = v;
+        *(float4*)(xs + n * SP_W + c4) = v;
     }
     __syncthreads();
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int n = rg; n < n_s; n += 16) {
-        const float4 v = *(const float4*)(xs + n * 64 + c4);
+    for (int n = rg; n < n_s; n += 32) {
+        const float4 v = *(const float4*)(xs + n * SP_W + c4);
         const float wn = w[n];
         acc.x = fmaf(wn, v.x, acc.x); acc.y = fmaf(wn, v.y, acc.y);
         acc.z = fmaf(wn, v.z, acc.z); acc.w = fmaf(wn, v.w, acc.w);
     }
     *(float4*)(&red[rg][c4]) = acc;
     __syncthreads();
-    if (tid < 64) {
+    if (tid < SP_W) {
         float m = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) m += red[q][tid];
+        for (int q = 0; q < 32; ++q) m += red[q][tid];
         mu[tid] = m;
         if (d0 + tid < D) mu_out[((long)e * B + b) * D + d0 + tid] = m;
     }
@@ -303,8 +320,8 @@ __global__ void __launch_bounds__(256) student_project_v4_kernel(const void* con
     // trace: sum_n w_n (x_n - mu)^2 over this slab
     float part = 0.f;
     if (live)
-        for (int n = rg; n < n_s; n += 16) {
-            const float4 v = *(const float4*)(xs + n * 64 + c4);
+        for (int n = rg; n < n_s; n += 32) {
+            const float4 v = *(const float4*)(xs + n * SP_W + c4);
             const float cx = v.x - m4.x, cy = v.y - m4.y, cz = v.z - m4.z, cw = v.w - m4.w;
             part = fmaf(w[n], fmaf(cx, cx, fmaf(cy, cy, fmaf(cz, cz, cw * cw))), part);
         }
@@ -313,17 +330,12 @@ __global__ void __launch_bounds__(256) student_project_v4_kernel(const void* con
     // A'[j, d] = sum_n I[n, j] w_n (x_n - mu)
     if (!live) return;
     float* Ab = Ap + ((long)e * B + b) * n_t * D + d0 + c4;
-    for (int j = rg; j < n_t; j += 16) {
+    for (int j = rg; j < n_t; j += 32) {
         const int n0 = range0 ? range0[j] : j, n1 = range1 ? range1[j] : j + 1;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int n = n0; n < n1; ++n) {
-            float coef = 1.f;
-            if (tap0) {
-                const float l1 = lam[n];
-                coef = (tap0[n] == j ? 1.f - l1 : 0.f) + (tap1[n] == j ? l1 : 0.f);
-            }
-            const float cw = coef * w[n];
-            const float4 v = *(const float4*)(xs + n * 64 + c4);
+            const float cw = tap0 ? (t0[n] == j ? c0[n] : 0.f) + (t1[n] == j ? c1[n] : 0.f) : w[n];
+            const float4 v = *(const float4*)(xs + n * SP_W + c4);
             a.x = fmaf(cw, v.x - m4.x, a.x); a.y = fmaf(cw, v.y - m4.y, a.y);
             a.z = fmaf(cw, v.z - m4.z, a.z); a.w = fmaf(cw, v.w - m4.w, a.w);
         }
@@ -541,23 +553,51 @@ __global__ void __launch_bounds__(1024) chol_f64_kernel(const double* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// W[b] = [ L_a^T L_b ; L_b ]   (2n x n, column-major fp32, leading dimension 2n)
-// grid = (ceil(n*n/256), batch), block = 256.  fp64 accumulate.
+// W[b] = [ L_a^T L_b ; L_b ]   (2n x n, column-major fp32, leading dimension 2n), fp64 accumulate.
+// stack_product_kernel: grid = batch, block = 256, both factors in LDS (n <= 98).
+// stack_product_global_kernel: grid = (ceil(n*n/256), batch), factors read from L2 (larger n).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) stack_product_kernel(const double* __restrict__ La,
-                                                            const double* __restrict__ Lb, long l_batch_stride,
-                                                            int n, float* __restrict__ W, long w_batch_stride,
-                                                            int lb_period) {
+__global__ void __launch_bounds__(256) stack_product_global_kernel(const double* __restrict__ La,
+                                                                   const double* __restrict__ Lb,
+                                                                   long l_batch_stride, int n, float* __restrict__ W,
+                                                                   long w_batch_stride, int lb_period) {
     const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * n) return;
     const int i = idx / n, j = idx - i * n;   // consecutive threads: consecutive j
     const double* A = La + (long)b * l_batch_stride;
-    const double* B = Lb + (long)(b % lb_period) * l_batch_stride;   // one teacher factor for all extraction layers
+    const double* B = Lb + (long)(b % lb_period) * l_batch_stride;
     double acc = 0.;
     for (int k = (i > j ? i : j); k < n; ++k) acc = fma(A[(long)k * n + i], B[(long)k * n + j], acc);
     float* Wb = W + (long)b * w_batch_stride;
     Wb[(long)j * 2 * n + i] = (float)acc;
     Wb[(long)j * 2 * n + n + i] = (float)B[(long)i * n + j];
+}
+
+__global__ void __launch_bounds__(256) stack_product_kernel(const double* __restrict__ La,
+                                                            const double* __restrict__ Lb, long l_batch_stride,
+                                                            int n, float* __restrict__ W, long w_batch_stride,
+                                                            int lb_period) {
+    // One workgroup per matrix: both factors staged in LDS (the first version read them element-wise from L2 inside
+    // the k loop: 0.13 ms at cfg-2 for 0.24 GFLOP).  sa[k * n + i] = L_a[k][i], sb[k * n + j] = L_b[k][j].
+    extern __shared__ __attribute__((aligned(16))) double sd[];
+    double* sa = sd;
+    double* sb = sd + (size_t)n * n;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double* A = La + (long)b * l_batch_stride;
+    const double* B = Lb + (long)(b % lb_period) * l_batch_stride;   // one teacher factor for all extraction layers
+    for (int idx = tid; idx < n * n; idx += 256) {
+        sa[idx] = A[idx];
+        sb[idx] = B[idx];
+    }
+    __syncthreads();
+    float* Wb = W + (long)b * w_batch_stride;
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int j = idx / n, i = idx - j * n;      // consecutive threads: consecutive i (rows of the output column j)
+        double acc = 0.;
+        for (int k = (i > j ? i : j); k < n; ++k) acc = fma(sa[k * n + i], sb[k * n + j], acc);
+        Wb[(long)j * 2 * n + i] = (float)acc;
+        Wb[(long)j * 2 * n + n + i] = (float)sb[i * n + j];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -833,7 +873,13 @@ int basd_chol_f64(const double* g, long g_batch_stride, int n, int batch, double
 int basd_stack_product(const double* la, const double* lb, long l_batch_stride, int n, int batch, int lb_period,
                        float* w, long w_batch_stride, hipStream_t stream) {
     BASD_CHECK_ARG(la && lb && w && n > 0 && batch > 0 && lb_period > 0);
-    stack_product_kernel<<<dim3((n * n + 255) / 256, batch), 256, 0, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride, lb_period);
+    const size_t lds = sizeof(double) * 2 * (size_t)n * n;
+    if (lds <= 78 * 1024) {           // two workgroups per CU
+        (void)hipFuncSetAttribute((const void*)stack_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024);
+        stack_product_kernel<<<batch, 256, lds, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride, lb_period);
+    } else {
+        stack_product_global_kernel<<<dim3((n * n + 255) / 256, batch), 256, 0, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride, lb_period);
+    }
     BASD_RETURN_LAST();
 }
 
@@ -889,7 +935,7 @@ int basd_student_grad_multi(const void* const* x_ptrs, int dtype, long sb, long 
 }
 
 // basd_student_project for all E extraction layers in one launch (x_ptrs: device table; omega + e * omega_e_stride;
-// mu (E, B, D), tr_s (E, B, ceil(D/64)), a_prime (E, B, n_t, D)).  Returns BASD_EUNSUPPORTED where the vectorised,
+// mu (E, B, D), tr_s (E, B, ceil(D/32)) -- 32-feature slabs here --, a_prime (E, B, n_t, D)).  Returns BASD_EUNSUPPORTED where the vectorised,
 // LDS-staged kernel does not apply (rows not 16-byte aligned, slab over 64 KB): call basd_student_project per layer.
 int basd_student_project_multi(const void* const* x_ptrs, int dtype, long sb, long sn, int E, int B, int n_s, int n_t,
                                int D, int ptrs_16B_aligned, const float* omega, long omega_e_stride, const int* tap0,
@@ -899,11 +945,11 @@ int basd_student_project_multi(const void* const* x_ptrs, int dtype, long sb, lo
     BASD_CHECK_ARG((n_t == n_s) == (tap0 == nullptr));
     BASD_CHECK_ARG(E <= 65535 && B <= 65535);
     const int esz = dtype == BASD_DTYPE_F32 ? 4 : 2;
-    const size_t lds = sizeof(float) * ((size_t)n_s * 64 + n_s);
+    const size_t lds = sizeof(float) * ((size_t)n_s * SP_W + 5 * (size_t)n_s);
     const bool ok = ptrs_16B_aligned && D % 4 == 0 && (sb * esz) % 16 == 0 && (sn * esz) % 16 == 0 &&
-                    (esz == 4 || D % 8 == 0) && lds <= 64 * 1024;
+                    (esz == 4 || D % 8 == 0) && lds <= 96 * 1024;
     if (!ok) return BASD_EUNSUPPORTED;
-    const dim3 grid((D + 63) / 64, B, E);
+    const dim3 grid((D + SP_W - 1) / SP_W, B, E);
     if (dtype == BASD_DTYPE_F32) {
         (void)hipFuncSetAttribute((const void*)student_project_v4_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         student_project_v4_kernel<float><<<grid, 256, lds, stream>>>(x_ptrs, sb, sn, n_s, n_t, D, omega, omega_e_stride, tap0, tap1, lam, range0, range1, mu, tr_s, a_prime);

@@ -1128,7 +1128,7 @@ long basd_tridiag_workspace_bytes(int n, int batch) {
 }
 
 static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
-                        void* work, MpRankOut rk, hipStream_t stream) {
+                        void* work, MpRankOut rk, hipStream_t stream, hipEvent_t mid_event = nullptr) {
     BASD_CHECK_ARG(a && d && e && tau && vh && work && n > 1 && batch > 0);
     BASD_CHECK_ARG((((uintptr_t)work) & 15) == 0);
     if (n > 4096) return BASD_EUNSUPPORTED;
@@ -1161,6 +1161,12 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
         hipError_t me = hipMemsetAsync(err, 0, 32, stream);        // no shared stage: the status words stay clean
         if (me != hipSuccess) return (int)me;
     }
+    // recorded behind the shared (multi-workgroup) stage: from here on the factorisation only occupies one CU per
+    // matrix, so work that was held back to keep the chip quiet for the spinning members may start
+    if (mid_event) {
+        hipError_t ee = hipEventRecord(mid_event, stream);
+        if (ee != hipSuccess) return (int)ee;
+    }
     rk.status = err;
     const bool fused_rank = tail && rk.rank_out && 2 * n <= 8 * TRI_TAIL_MAX;
     if (tail) {
@@ -1186,11 +1192,12 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
 // (nullable): pinned host memory of rank_count + 8 ints -- the ranks, then the factorisation's 8 status words.
 int basd_tridiag_ranked(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
                         void* work, int rank_count, double factor, int cap, int* rank_out, int* host_mirror,
-                        hipStream_t stream) {
+                        void* mid_event, hipStream_t stream) {
     BASD_CHECK_ARG(rank_out && rank_count > 0 && rank_count <= batch);
     if (n > 8192) return BASD_EUNSUPPORTED;
     return tridiag_impl(a, a_batch_stride, n, batch, d, e, tau, vh, work,
-                        MpRankOut{rank_out, host_mirror, nullptr, factor, cap, rank_count}, stream);
+                        MpRankOut{rank_out, host_mirror, nullptr, factor, cap, rank_count}, stream,
+                        (hipEvent_t)mid_event);
 }
 
 // All eigenvalues (descending) of the tridiagonals by Sturm bisection.
