@@ -237,6 +237,11 @@ int basd_gram_f64(const float* p, long p_batch_stride, int n, int D, int batch, 
                   hipStream_t stream);
 
 /* fp64 Cholesky of (possibly singular) PSD matrices; L full row-major. */
+/* basd_gram_f64 with the contraction split over `splits` workgroups per matrix (few matrices, long feature axis);
+ * slabs: splits * batch * n * n doubles of scratch, folded in a fixed order; g contiguous (batch, n, n). */
+int basd_gram_f64_split(const float* p, long p_batch_stride, int n, int D, int batch, int splits, double* slabs,
+                        double* g, hipStream_t stream);
+
 int basd_chol_f64(const double* g, long g_batch_stride, int n, int batch, double* l, long l_batch_stride,
                   hipStream_t stream);
 
@@ -305,8 +310,17 @@ typedef struct BasdProcrustesArgs {
     float* W; float* sigma; int* jflags; int* sweeps;
     float* tr_t; float* nuc; float* loss_b; float* k_prime;
     float* h; float* dx; const float* grad_layers;
+    double* g_slabs; long g_splits;     /* nullable / <= 1: teacher Gram unsplit; else g_splits * G*B*n*n doubles of scratch */
 } BasdProcrustesArgs;
 int basd_procrustes_forward_fused(const BasdProcrustesArgs* args, hipStream_t stream);
+
+/* The base criterion of BASDLoss (combined.py:56) when it is the stock torch.nn.CrossEntropyLoss (mean reduction, no
+ * class weights): per-row losses (already divided by the number of rows that are not ignored; loss = their sum) and
+ * d loss / d logits in ONE launch.  Exactly one of labels (int64 class indices, B) / probs (fp32 soft targets (B, C),
+ * row stride pld); label smoothing as in torch: t' = (1 - eps) t + eps / C. */
+int basd_cross_entropy(const void* logits, int dtype, long ld, int B, int C, const long* labels, const float* probs,
+                       long pld, float label_smoothing, long ignore_index, float* row_loss, float* dlogits,
+                       hipStream_t stream);
 
 /* ---- CU partitions (hipExtStreamCreateWithCUMask) --------------------------------------------------- */
 

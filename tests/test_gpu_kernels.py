@@ -429,3 +429,32 @@ def test_centered_grams_fold_means_from_projection_epilogue(dev):
     c = zd - zd.mean(0)
     assert _rel(out[0], zd.T @ zd / M) < 5e-6
     assert _rel(out[1], c.T @ c) < 5e-6
+
+
+@pytest.mark.parametrize("soft", [False, True])
+@pytest.mark.parametrize("eps", [0.0, 0.1])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_cross_entropy_matches_torch(dev, soft, eps, dtype):
+    """The one-launch cross entropy (loss + logits gradient) against torch.nn.CrossEntropyLoss: hard labels (with an
+    ignored row), soft (mixup-style) targets, label smoothing, fp32 / bf16 logits."""
+    from basd_amd import losses
+    g = torch.Generator().manual_seed(3)
+    B, C = 37, 1000
+    logits = (torch.randn(B, C, generator=g) * 3).to(dev).to(dtype)
+    if soft:
+        targets = torch.softmax(torch.randn(B, C, generator=g) * 2, dim=1).to(dev)
+    else:
+        targets = torch.randint(0, C, (B,), generator=g).to(dev)
+        targets[5] = -100
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=eps)
+    a = logits.clone().requires_grad_(True)
+    b = logits.clone().float().requires_grad_(True)
+    la = losses._base_loss(crit, a, targets)
+    lb = crit(b, targets)
+    assert type(la.grad_fn).__name__.startswith("_FusedCrossEntropy")
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
+    assert abs(la.item() - lb.item()) <= tol * abs(lb.item())
+    (la * 1.7).backward()
+    (lb * 1.7).backward()
+    ref = b.grad
+    assert ((a.grad.float() - ref).abs().max() / ref.abs().max()).item() < (1e-5 if dtype == torch.float32 else 1e-2)

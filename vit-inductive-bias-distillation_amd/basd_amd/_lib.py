@@ -46,11 +46,13 @@ SIGNATURES = {
     "basd_grassmann_distance": [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp],
     "basd_selector_tail": [vp] * 10 + [i32, i32, i32, i32] + [vp] * 14 + [vp],
     "basd_sqrt_clamp": [vp, vp, i64, vp],
+    "basd_cross_entropy": [vp, i32, i64, i32, i32, vp, vp, i64, f32, i64, vp, vp, vp],
     "basd_token_weights": [vp, i32, vp, i32, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp,
                            vp, vp, vp, vp, vp, vp],
     "basd_student_project": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "basd_teacher_center": [vp, i32, vp, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_gram_f64": [vp, i64, i32, i32, i32, vp, i64, vp],
+    "basd_gram_f64_split": [vp, i64, i32, i32, i32, i32, vp, vp, vp],
     "basd_chol_f64": [vp, i64, i32, i32, vp, i64, vp],
     "basd_stack_product": [vp, vp, i64, i32, i32, i32, vp, i64, vp],
     "basd_procrustes_finalize": [vp, i64, vp, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp,
@@ -88,7 +90,8 @@ class ProcrustesArgs(C.Structure):
         + [(n, vp) for n in ("atap0", "atap1", "alam", "tap0", "tap1", "lam", "range0", "range1", "g0", "g1", "glam",
                              "omega", "omega_t", "raw", "mu_t", "tc", "mu_s", "tr_part", "tr_s", "a_prime", "g_all",
                              "l_all", "W", "sigma", "jflags", "sweeps", "tr_t", "nuc", "loss_b", "k_prime", "h", "dx",
-                             "grad_layers")]
+                             "grad_layers", "g_slabs")]
+        + [("g_splits", i64)]
     )
 
 

@@ -187,6 +187,42 @@ class _ProcrustesLayers(torch.autograd.Function):
         return (g_mix, None, None, ctx_zero(ctx, grad_layers), None, None, *grads)
 
 
+class _FusedCrossEntropy(torch.autograd.Function):
+    """torch.nn.CrossEntropyLoss (mean, no class weights) as ONE kernel that leaves the loss and the unit gradient of the
+    logits; backward is one scaling.  (The stock module queues ~15 micro-kernels for forward + backward, and their
+    host time sits between the rank read-back and the end of the step.)"""
+
+    @staticmethod
+    def forward(ctx, logits, targets, eps, ignore_index):
+        x = logits if logits.stride(1) == 1 else logits.contiguous()
+        B, C = x.shape
+        row = torch.empty((B,), device=x.device, dtype=torch.float32)
+        dlog = torch.empty((B, C), device=x.device, dtype=torch.float32)
+        hard = not targets.is_floating_point()
+        t = targets.contiguous() if hard else targets.float().contiguous()
+        ops._lib.call("basd_cross_entropy", x.data_ptr(), ops._dtype_code(x), x.stride(0), B, C,
+                      t.data_ptr() if hard else None, None if hard else t.data_ptr(), 0 if hard else t.stride(0),
+                      float(eps), int(ignore_index), row.data_ptr(), dlog.data_ptr(), ops._stream())
+        ctx.save_for_backward(dlog)
+        ctx.dtype = logits.dtype
+        return row.sum().to(logits.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return (dlog * g).to(ctx.dtype), None, None, None
+
+
+def _base_loss(criterion: nn.Module, logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """``criterion(logits, targets)``; the stock cross entropy on CUDA tensors takes the fused kernel."""
+    if (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.reduction == "mean"
+            and logits.is_cuda and logits.dim() == 2 and logits.dtype in (torch.float32, torch.bfloat16)
+            and ((targets.dim() == 1 and targets.dtype == torch.int64)
+                 or (targets.dim() == 2 and targets.is_floating_point() and targets.shape == logits.shape))):
+        return _FusedCrossEntropy.apply(logits, targets, criterion.label_smoothing, criterion.ignore_index)
+    return criterion(logits, targets)
+
+
 class _UWSOCombine(torch.autograd.Function):
     """(ce, geo_layers (E,)) -> w_ce * ce + w_geo * mean(geo_layers), UW-SO weights w_i = (1/L_i) / sum_j (1/L_j)
     computed from the detached loss values (combined.py:78-85).  One autograd node instead of the eight the
@@ -226,7 +262,7 @@ class _SingleTeacherTotal(torch.autograd.Function):
         pc = ops.procrustes_forward(list(students), teachers, attns, ones.view(-1, 1), has_cls, need_backward=need_bwd,
                                     need_mix_grad=False, grad_layers=ones if need_bwd else None)
         geo_layers = pc.loss_b.mean(dim=1)
-        ctx.unit_grads = list(pc.dx.unbind(0)) if pc.dx is not None else None
+        ctx.unit_grads = pc.dx          # (E, B, N_s, D_s): gradients for a unit upstream gradient, one buffer
         ctx.consumer = ops.CONSUMER_STREAM         # set when this node runs on a partition stream (BASDLoss.forward)
         # UW-SO (combined.py:78-85) on the detached values
         vals = torch.stack([ce.detach(), geo_layers.mean().to(ce.dtype)])
@@ -247,16 +283,15 @@ class _SingleTeacherTotal(torch.autograd.Function):
         grads = [None] * ctx.n_students
         if ctx.unit_grads is not None:
             scale = gw[1] / ctx.n_students
-            grads = [(u * scale).to(dt) if ctx.needs_input_grad[5 + i] else None
-                     for i, (u, dt) in enumerate(zip(ctx.unit_grads, ctx.dtypes))]
-            if ctx.consumer is not None:           # allocated on this (partition) stream, read on the caller's
-                for gr in grads:
-                    if gr is not None:
-                        gr.record_stream(ctx.consumer)
+            scaled = ctx.unit_grads * scale         # ONE launch over all layers (they share the upstream scalar)
+            if ctx.consumer is not None:            # allocated on this (partition) stream, read on the caller's
+                scaled.record_stream(ctx.consumer)
+            grads = [scaled[i].to(dt) if ctx.needs_input_grad[5 + i] else None for i, dt in enumerate(ctx.dtypes)]
         zero = None
         if ctx.zero_shape is not None and ctx.needs_input_grad[2]:
             zero = torch.zeros(ctx.zero_shape[0], device=g.device, dtype=ctx.zero_shape[1])
         ops.trace("bwd_total_out")
+        ops.gpu_mark("bwd_procrustes_end")
         return (gw[0] if ctx.needs_input_grad[0] else None, None, zero, None, None, *grads)
 
 
@@ -479,11 +514,13 @@ class GrassmannianLayerSelector(nn.Module):
         if ops.HOST_TRACE is not None:             # diagnostics (tools/host_timeline.py): GPU time of the teacher chain
             chain_t0 = torch.cuda.Event(enable_timing=True)
             chain_t0.record()
+        ops.gpu_mark("chain_begin")
         if student_stream is not None:
             student_stream.wait_stream(cur)
             # two chains: give the teacher stream its first (large) launch before the host queues the
             # student chain, so both start together
             projected = self._teacher_projections(teachers)
+            ops.gpu_mark("teacher_projected")
 
         def student_chain(gate=None):
             """centred Grams -> eigen-solve of the E student layers; ``gate``: event the chain waits for first"""
@@ -524,6 +561,7 @@ class GrassmannianLayerSelector(nn.Module):
 
         # ---- teacher side: projection, Grams, eigen-solve, MP ranks ----
         g_u, g_c, M, t_stack = self._teacher_grams(teachers, projected)
+        ops.gpu_mark("teacher_grams")
         same = t_stack is not None
         o_c = L if same else 0
         if not same:
@@ -547,6 +585,7 @@ class GrassmannianLayerSelector(nn.Module):
                 ts = ops.tridiagonalise(t_stack, mp_rank=(M, d_s, d_s - 1, L, pin, gate))
                 st["t_ts"] = ts
                 st["ranks_dev"] = ts.ranks
+                ops.gpu_mark("ranks_ready")
                 ready = torch.cuda.Event(enable_timing=chain_t0 is not None)
                 ready.record()
                 st["rank_ready"] = (pin, ready)
@@ -951,8 +990,14 @@ class BASDLoss(nn.Module):
                 t.record_stream(side2)
             with torch.cuda.stream(side):
                 spectra = sel._spectra_async(students, teachers, student_stream=side2, eig_streams=eig)
+            # what the selector tail of THIS step has to wait for (it may be queued after later steps' chains)
+            chain_done = []
+            for st_ in ((eig[0], eig[1]) if part else (side, side2)):
+                ev = torch.cuda.Event()
+                ev.record(st_)
+                chain_done.append(ev)
             ops.trace("chains_queued")
-            ce_loss = self.base_criterion(student_output, targets)     # queued behind the chains' first launches
+            ce_loss = _base_loss(self.base_criterion, student_output, targets)     # behind the chains' first launches
             # softmax over ONE logit: the mixing weights are exactly 1 and d loss / d temperature exactly 0
             mix = ops._device_consts((1.0,) * len(students), torch.float32, main.device).view(-1, 1)
             if part:
@@ -975,20 +1020,25 @@ class BASDLoss(nn.Module):
                                                               sel.log_temperatures, teachers, attns, *students)
             ops.trace("procrustes_queued")
             tail = part["tail"] if part else self._selector_stream(main.device, 3 * lane + 2)
-            chain_ends = (eig[0], eig[1]) if part else (side, side2)
 
-            def selector_tail():
-                # The host reads the ranks here (and raises on rank 0 like the reference).  The rest of the selector
-                # (eigenvectors, principal angles) goes to a third stream: the next step's eigen-solve chains do
-                # not queue behind it, and nothing of it feeds this loss when there is one teacher layer.
+            def read_ranks():
+                # The host reads the ranks here (and raises on rank 0 like the reference).
                 if "rank_ready" in spectra:
-                    ranks = sel._read_ranks(spectra, keys)              # waits on the rank kernel's event
-                else:
-                    with torch.cuda.stream(side):                       # plain read-back behind both chains
-                        side.wait_stream(side2)
-                        ranks = sel._read_ranks(spectra, keys)
-                tail.wait_stream(chain_ends[0])
-                tail.wait_stream(chain_ends[1])
+                    return sel._read_ranks(spectra, keys)               # waits on the rank kernel's event
+                with torch.cuda.stream(side):                           # plain read-back behind both chains
+                    side.wait_stream(side2)
+                    return sel._read_ranks(spectra, keys)
+
+            def queue_tail(ranks, gate_tail=False):
+                # The rest of the selector (eigenvectors, principal angles) goes to a third stream: the next step's
+                # eigen-solve chains do not queue behind it, and nothing of it feeds this loss when there is one
+                # teacher layer -- so it is not even queued in this call (see below).
+                for ev in chain_done:
+                    tail.wait_event(ev)
+                # queued one step later (see below): then also behind that step's multi-workgroup tridiagonalisation
+                # stage, like its student chain -- the members of that stage must not queue for CUs behind these kernels
+                if gate_tail and getattr(sel, "_gate_event", None) is not None:
+                    ops.stream_wait_event(tail, sel._gate_event)
                 ops.trace("tail_waits")
                 # only what the tail reads needs marking (every marked block costs an event when it is freed)
                 _record_stream([spectra.get("t_ts"), spectra.get("s_ts"), spectra["ranks_dev"],
@@ -999,10 +1049,13 @@ class BASDLoss(nn.Module):
                 with torch.cuda.stream(tail):
                     sel._angles_from_spectra(spectra, keys, ranks_host=ranks)
                 ops.trace("tail_queued")
+
+            def selector_tail():
+                queue_tail(read_ranks())
         else:
             selector_tail = None
             sel.finish_pending()
-            ce_loss = self.base_criterion(student_output, targets)
+            ce_loss = _base_loss(self.base_criterion, student_output, targets)
             mix = sel.mixing_weights(students, keys, teachers)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), False, None, teachers, attns,
                                                  *students)
@@ -1011,10 +1064,13 @@ class BASDLoss(nn.Module):
         ops.trace("combine_queued")
         if selector_tail is not None:
             if self.sync_ranks:
-                # the reference's timing: ranks read (and rank 0 raised) inside this call; called last so that
-                # everything else of the step is queued before the host blocks
+                # The reference's timing: ranks read (and rank 0 raised) inside this call; called last so that
+                # everything else of the step is queued before the host blocks.  While the host is about to idle
+                # waiting for this step's ranks it first queues the PREVIOUS step's selector tail (~0.15 ms of
+                # launches that would otherwise sit between the read-back and the caller's backward).
                 sel.finish_pending()
-                selector_tail()
+                ranks = read_ranks()
+                sel._pending_tail = lambda: queue_tail(ranks, gate_tail=True)
             else:
                 # deferred: the PREVIOUS step's ranks are read now (its rank kernel finished long ago; if not,
                 # this wait is the back-pressure that keeps the host at most one step ahead), this step's by the

@@ -66,6 +66,16 @@ def trace(label: str) -> None:
         HOST_TRACE.append((label, time.perf_counter()))
 
 
+GPU_MARKS: list | None = None    # (label, timing event recorded on the current stream) while switched on (tools/step_clock.py)
+
+
+def gpu_mark(label: str) -> None:
+    if GPU_MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        GPU_MARKS.append((label, ev))
+
+
 def _tok3(x: torch.Tensor) -> tuple[int, int, int, int, int, int]:
     """(ptr, dtype, sb, sn, sd, rows_per_batch) of a (B, N, D) or (M, D) view."""
     if x.dim() == 2:
@@ -561,7 +571,13 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     k_prime = torch.empty((E, B, n, n), **f32) if need_bwd else None
     terms = torch.empty((4, E, B), **f32)                                # tr_s, tr_t, nuc, loss_b
     tc = torch.empty((G, B, n, d_t), **f32)
-    g_all = torch.empty((EB + GB, n, n), device=dev, dtype=torch.float64)
+    # teacher Gram: few matrices with a long feature axis -> split the contraction over several workgroups each
+    g_splits = 1
+    if GB < 1024 and d_t >= 512:
+        g_splits = max(1, min(1024 // GB, d_t // 256, 16))
+    g_all = torch.empty((EB + GB + (g_splits * GB if g_splits > 1 else 0), n, n), device=dev, dtype=torch.float64)
+    g_slabs = g_all[EB + GB:] if g_splits > 1 else None
+    g_all = g_all[:EB + GB]
     l_all = torch.empty_like(g_all)
     W = torch.empty((EB, n, 2 * n), **f32)      # memory == column-major (2n x n)
     # transient fp32 scratch in one allocation
@@ -607,7 +623,10 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     args.a_prime, args.g_all, args.l_all, args.W = a_prime.data_ptr(), g_all.data_ptr(), l_all.data_ptr(), W.data_ptr()
     args.sigma, args.jflags, args.sweeps, args.k_prime = sigma.data_ptr(), ints.data_ptr(), _ptr(sweeps), _ptr(k_prime)
     args.h, args.dx, args.grad_layers = _ptr(h), _ptr(dx), _ptr(grad_layers)
+    args.g_slabs, args.g_splits = _ptr(g_slabs), g_splits
+    gpu_mark("procrustes_begin")
     _lib.call("basd_procrustes_forward_fused", ctypes.addressof(args), _stream())
+    gpu_mark("procrustes_end")
     del host_ptrs
 
     mixgrad = None

@@ -50,7 +50,11 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
     const long nn = (long)n * n;
     const int EB = E * B, GB = G * B;
     BASD_TRY(basd_gram_f64(a->a_prime, (long)n * d_s, n, d_s, EB, a->g_all, nn, st));
-    BASD_TRY(basd_gram_f64(a->tc, (long)n * d_t, n, d_t, GB, a->g_all + (long)EB * nn, nn, st));
+    if (a->g_slabs && a->g_splits > 1)
+        BASD_TRY(basd_gram_f64_split(a->tc, (long)n * d_t, n, d_t, GB, (int)a->g_splits, a->g_slabs,
+                                     a->g_all + (long)EB * nn, st));
+    else
+        BASD_TRY(basd_gram_f64(a->tc, (long)n * d_t, n, d_t, GB, a->g_all + (long)EB * nn, nn, st));
     BASD_TRY(basd_chol_f64(a->g_all, nn, n, EB + GB, a->l_all, nn, st));
     BASD_TRY(basd_stack_product(a->l_all, a->l_all + (long)EB * nn, nn, n, EB, GB, a->W, 2 * nn, st));
     BASD_TRY(basd_jacobi_onesided(a->W, 2 * nn, n, 2 * n, n, EB, nullptr, a->sigma, n, (int)a->max_sweeps, 0.f,

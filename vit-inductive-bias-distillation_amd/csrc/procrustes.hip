@@ -417,10 +417,14 @@ __global__ void __launch_bounds__(256) teacher_center_kernel(const void* const* 
 // ---------------------------------------------------------------------------
 constexpr int G64_BK = 32, G64_LD = 36, G64_TPW = 8;
 
+// blockIdx.y = split s of gridDim.y over the contraction index: the split handles D-chunks s, s + S, ... and writes its
+// partial Gram to G + s * g_split_stride (gram_f64_reduce_kernel folds them in a fixed order).
 __global__ void __launch_bounds__(1024) gram_f64_kernel(const float* __restrict__ P, long p_batch_stride, int n, int D,
-                                                        double* __restrict__ G, long g_batch_stride) {
+                                                        double* __restrict__ G, long g_batch_stride,
+                                                        long g_split_stride) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // (nt*16) x G64_LD
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    G += (long)blockIdx.y * g_split_stride;
     const int nt = (n + 15) / 16, ntiles = nt * (nt + 1) / 2;
     const float* Pb = P + (long)b * p_batch_stride;
     f64x4 acc[G64_TPW];
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(1024) gram_f64_kernel(const float* __restrict_
     }
     const int rows_pad = nt * 16;
     const int i16 = lane & 15, kq = lane >> 4;
-    for (int k0 = 0; k0 < D; k0 += G64_BK) {
+    for (int k0 = blockIdx.y * G64_BK; k0 < D; k0 += G64_BK * gridDim.y) {
         __syncthreads();
         for (int idx = tid; idx < rows_pad * (G64_BK / 4); idx += blockDim.x) {
             const int r = idx / (G64_BK / 4), c4 = (idx - r * (G64_BK / 4)) * 4, k = k0 + c4;
@@ -491,6 +495,16 @@ __global__ void __launch_bounds__(1024) gram_f64_kernel(const float* __restrict_
             }
         }
     }
+}
+
+// G[i] = sum_s slabs[s][i]  (fixed order: deterministic).  grid = ceil(count/256), block = 256.
+__global__ void __launch_bounds__(256) gram_f64_reduce_kernel(const double* __restrict__ slabs, long split_stride,
+                                                              int splits, long count, double* __restrict__ G) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double acc = 0.;
+    for (int s2 = 0; s2 < splits; ++s2) acc += slabs[(long)s2 * split_stride + i];
+    G[i] = acc;
 }
 
 // ---------------------------------------------------------------------------
@@ -855,7 +869,25 @@ int basd_gram_f64(const float* p, long p_batch_stride, int n, int D, int batch, 
     if (waves < 4) waves = ntiles < 4 ? ntiles : 4;
     if (waves > 16) return BASD_EUNSUPPORTED;   // n > 240
     const size_t lds = sizeof(float) * (size_t)nt * 16 * G64_LD;
-    gram_f64_kernel<<<batch, 64 * waves, lds, stream>>>(p, p_batch_stride, n, D, g, g_batch_stride);
+    gram_f64_kernel<<<batch, 64 * waves, lds, stream>>>(p, p_batch_stride, n, D, g, g_batch_stride, 0);
+    BASD_RETURN_LAST();
+}
+
+// The same with the contraction split over `splits` workgroups per matrix (few matrices with a long feature axis: the
+// teacher side, 256 x (49 x 2048) at cfg-2, left three quarters of the CUs idle).  slabs: splits * batch * n * n doubles
+// of scratch; g: contiguous (batch, n, n).
+int basd_gram_f64_split(const float* p, long p_batch_stride, int n, int D, int batch, int splits, double* slabs,
+                        double* g, hipStream_t stream) {
+    BASD_CHECK_ARG(p && g && slabs && n > 0 && D > 0 && batch > 0 && splits >= 1 && splits <= 64);
+    BASD_CHECK_ARG(((uintptr_t)p & 15) == 0 && D % 4 == 0 && p_batch_stride % 4 == 0);
+    const int nt = (n + 15) / 16, ntiles = nt * (nt + 1) / 2;
+    int waves = (ntiles + G64_TPW - 1) / G64_TPW;
+    if (waves < 4) waves = ntiles < 4 ? ntiles : 4;
+    if (waves > 16) return BASD_EUNSUPPORTED;   // n > 240
+    const size_t lds = sizeof(float) * (size_t)nt * 16 * G64_LD;
+    const long count = (long)batch * n * n;
+    gram_f64_kernel<<<dim3(batch, splits), 64 * waves, lds, stream>>>(p, p_batch_stride, n, D, slabs, (long)n * n, count);
+    gram_f64_reduce_kernel<<<(unsigned)((count + 255) / 256), 256, 0, stream>>>(slabs, count, splits, count, g);
     BASD_RETURN_LAST();
 }
 

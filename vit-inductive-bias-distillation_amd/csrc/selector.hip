@@ -159,3 +159,87 @@ int basd_selector_tail(const float* t_d, const float* t_e, const float* t_tau, c
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Base criterion of BASDLoss (reference combined.py:56) when it is the stock torch.nn.CrossEntropyLoss (mean reduction,
+// no class weights): loss and d loss / d logits in ONE launch instead of the ~15 micro-kernels torch queues for the
+// forward and backward of log_softmax / nll / label smoothing -- their host time sits between the rank read-back and
+// the end of the step.   row_loss[b] = -sum_c t'_c log softmax(x_b)_c,  t' = (1 - eps) t + eps / C;
+// hard labels: t = one-hot(y_b), rows with y_b == ignore_index contribute nothing; soft labels: t = probs[b].
+// dlogits[b][c] = (softmax_c - t'_c) / count  (count = rows not ignored; the caller scales by the upstream gradient).
+// grid = B, block = 256.  Accumulation in fp32 with the row maximum subtracted, like ATen.
+// ---------------------------------------------------------------------------
+namespace basd {
+template <typename T>
+__global__ void __launch_bounds__(256) cross_entropy_kernel(const T* __restrict__ logits, long ld, int C,
+                                                            const long* __restrict__ labels,
+                                                            const float* __restrict__ probs, long pld, float eps,
+                                                            long ignore_index, float* __restrict__ row_loss,
+                                                            float* __restrict__ dlogits) {
+    __shared__ float red[32];
+    const int b = blockIdx.x, tid = threadIdx.x, B = gridDim.x;
+    const T* x = logits + (long)b * ld;
+    float* dx = dlogits + (long)b * C;
+    const long y = labels ? labels[b] : -1;
+    const bool ignored = labels && y == ignore_index;
+    // mean over the rows that are not ignored (every workgroup counts them itself: B labels from L2)
+    float cnt = 0.f;
+    if (labels) {
+        for (int r = tid; r < B; r += 256) cnt += labels[r] != ignore_index ? 1.f : 0.f;
+        cnt = block_sum(cnt, red);
+        __syncthreads();
+    } else {
+        cnt = (float)B;
+    }
+    const float inv_count = 1.f / fmaxf(cnt, 1.f);
+    if (ignored) {
+        for (int c = tid; c < C; c += 256) dx[c] = 0.f;
+        if (tid == 0) row_loss[b] = 0.f;
+        return;
+    }
+    float m = -3.4e38f;
+    for (int c = tid; c < C; c += 256) m = fmaxf(m, to_f32(x[c]));
+    m = wave_max(m);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f, sx = 0.f, tx = 0.f;          // sum exp, sum x (uniform part), sum t x (target part)
+    for (int c = tid; c < C; c += 256) {
+        const float v = to_f32(x[c]) - m;
+        s += expf(v);
+        sx += v;
+        if (probs) tx = fmaf(probs[(long)b * pld + c], v, tx);
+    }
+    s = block_sum(s, red);
+    sx = block_sum(sx, red);
+    if (probs) tx = block_sum(tx, red);
+    else tx = to_f32(x[y]) - m;
+    const float lse = logf(s);
+    // -sum_c t'_c (v_c - lse) = lse - (1 - eps) tx - eps/C sx        (sum_c t'_c = 1); already divided by the count
+    if (tid == 0) row_loss[b] = (lse - (1.f - eps) * tx - eps / (float)C * sx) * inv_count;
+    const float inv_s = 1.f / s;
+    for (int c = tid; c < C; c += 256) {
+        const float p = expf(to_f32(x[c]) - m) * inv_s;
+        const float t = probs ? probs[(long)b * pld + c] : (c == y ? 1.f : 0.f);
+        dx[c] = (p - ((1.f - eps) * t + eps / (float)C)) * inv_count;
+    }
+}
+}  // namespace basd
+
+extern "C" {
+// logits: (B, C) fp32 / bf16 with row stride ld; exactly one of labels (int64, B) / probs (fp32, (B, C), row stride pld).
+int basd_cross_entropy(const void* logits, int dtype, long ld, int B, int C, const long* labels, const float* probs,
+                       long pld, float label_smoothing, long ignore_index, float* row_loss, float* dlogits,
+                       hipStream_t stream) {
+    BASD_CHECK_ARG(logits && row_loss && dlogits && B > 0 && C > 0 && ((labels != nullptr) != (probs != nullptr)));
+    if (dtype == BASD_DTYPE_F32)
+        basd::cross_entropy_kernel<float><<<B, 256, 0, stream>>>((const float*)logits, ld, C, labels, probs, pld, label_smoothing, ignore_index, row_loss, dlogits);
+    else if (dtype == BASD_DTYPE_BF16)
+        basd::cross_entropy_kernel<__hip_bfloat16><<<B, 256, 0, stream>>>((const __hip_bfloat16*)logits, ld, C, labels, probs, pld, label_smoothing, ignore_index, row_loss, dlogits);
+    else
+        return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+}  // extern "C"
