@@ -56,10 +56,15 @@ def algorithmic_bytes(shape: synth.LossShape, batch: int, elem: int = 4) -> dict
     return {"fwd": fwd, "bwd": fwd + grad, "step": 2 * fwd + grad, "student": student, "student_grad": grad}
 
 
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+
+
 def measured_traffic(cfg: str) -> dict:
-    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/r01_traffic.json,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE); {} when not collected."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/r02_traffic.json, written by
+    tools/pmc_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE); {} when not
+    collected.  These are numbers of an EARLIER profiled run of this command, copied into the line: `traffic_source`
+    says so."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_FILE)
     try:
         with open(path) as f:
             return json.load(f).get(cfg, {})
@@ -212,8 +217,10 @@ def main() -> None:
     batch = args.batch or shape.batch
     mod = build(shape, args.config, device)
     # per-rank minibatch (weak scaling): seed 1234 + rank, generated once, resident in HBM
-    inp = synth.make_inputs(shape, 1234 + rank, batch=batch, device=device, strided=not args.contiguous,
-                            attn_on_device=shape.layers_t > 1)
+    # cfg-5 (BASELINE.json configs[4]) hands bf16 features over; the kernels widen them and compute in fp32
+    in_dtype = torch.bfloat16 if args.config == "cfg5" else torch.float32
+    inp = synth.make_inputs(shape, 1234 + rank, batch=batch, device=device, dtype=in_dtype,
+                            strided=not args.contiguous, attn_on_device=shape.layers_t > 1)
     leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
     logits = inp.logits.detach().requires_grad_(True)
     bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), device, slots=2)
@@ -226,11 +233,14 @@ def main() -> None:
         loss = step()
     mod.layer_selector.finish_pending()       # deferred selector tail of the last warm-up step: outside the timing
     bucket.wait(all_slots=True)
-    # dominant kernel: tridiag_kernel (Householder tridiagonalisation of the selector's Gram matrices; the
-    # entry point basd_tridiag is exactly one launch).  HIP events are recorded on the stream it is queued on.
-    dominant = "basd_tridiag" if ops.EIG_SOLVER == "tridiag" else "basd_jacobi_onesided"
+    # Kernels reported with a roofline object, timed live with HIP events recorded on the stream they are queued on
+    # (each of these entry points is one kernel, plus a small fold for the Gram):
+    #   basd_tridiag_ranked / basd_tridiag   Householder tridiagonalisation (two kernels: shared stage + tail stage)
+    #   basd_syrk_multi                      symmetric Gram matrices on the fp32 MFMA
+    #   basd_colmean_multi                   column sums: the purest HBM stream of the step
+    timed = {"basd_tridiag", "basd_tridiag_ranked", "basd_syrk_multi", "basd_colmean_multi", "basd_jacobi_onesided"}
     _lib.timing = {}
-    _lib.timed_names = None if args.breakdown else {dominant, "basd_syrk_multi"}
+    _lib.timed_names = None if args.breakdown else timed
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -262,42 +272,51 @@ def main() -> None:
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         ab = algorithmic_bytes(shape, batch)
-        spans = sorted(per_call.get(dominant, [0.0]))
-        d_s = shape.d_s
-        if dominant == "basd_tridiag":
-            # two launches per step (teacher matrices, student matrices) on two streams; take the student one
-            # (E matrices; the longer).  Algorithmic bytes of a launch: every matrix read once, its reflectors
-            # written once.
-            launches = 1
-            n_mats = shape.points
-            kernel_name = "tridiag_kernel (Householder tridiagonalisation of the E student Gram matrices)"
-            note = ("latency bound, not a stream: D_s - 1 dependent Householder steps, each an L2 round trip plus a "
-                    "tagged-granule hand-off between the workgroups sharing a matrix (DESIGN.md section 5); the "
-                    "roofline-bound kernel of the path is reported under roofline_mfma")
+        d_s, E, L = shape.d_s, shape.points, shape.layers_t
+        traffic = measured_traffic(args.config)
+        traffic_source = (f"{TRAFFIC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
+                          "command (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), not collected in this run"
+                          if traffic else None)
+
+        def longest(names):
+            """mean duration (ms) of the LONGER of the calls of an entry point per step (student-side call), and the count"""
+            calls = [c for n in names for c in per_call.get(n, [])]
+            if not calls:
+                return 0.0, 0
+            per_step = max(1, round(len(calls) / args.steps))
+            top = sorted(calls)[-args.steps:] if per_step > 1 else calls
+            return sum(top) / len(top), per_step
+
+        # --- dominant kernel by GPU time: the tridiagonalisation of the selector's Gram matrices
+        if ops.EIG_SOLVER == "tridiag":
+            eig_ms, eig_calls = longest(["basd_tridiag", "basd_tridiag_ranked"])
+            n_mats = E if L == 1 else max(E, 2 * L)
+            kernel_name = ("tridiag_kernel + tridiag_tail_kernel (Householder tridiagonalisation of the student Gram "
+                           "matrices; the teacher-side call of the same entry point runs beside it)")
+            note = ("latency-bound, neither an HBM stream nor MFMA work: n - 1 dependent Householder steps (first stage: "
+                    "matrix shared by up to 16 workgroups, one L2 round trip + granule hand-off per step; last 256 steps: "
+                    "matrix in one CU's registers, four workgroup barriers per step).  `bound` is kept to the contract's "
+                    "vocabulary; the HBM fraction says how far from a stream this kernel is by construction.  The "
+                    "roofline-bound kernels of the path are under roofline_mfma / roofline_hbm_stream.")
         else:
-            nblk = ((d_s + 15) // 16 + 1) // 2 * 2
-            launches = ops.MAX_SWEEPS * (nblk - 1)
-            n_mats = 2 * shape.layers_t + shape.points
+            eig_ms, eig_calls = longest(["basd_jacobi_onesided"])
+            n_mats = 2 * L + E
             kernel_name = "jacobi_block_round_kernel (block one-sided Jacobi, symmetric eigen-solves of the selector)"
             note = "latency-bound chain of dependent pair-steps, not an HBM stream (DESIGN.md section 5)"
-        eig = spans[-args.steps:] if len(spans) >= args.steps else spans
-        eig_ms = sum(eig) / max(1, len(eig))
-        solve_bytes = n_mats * 2 * d_s * d_s * 4
-        launch_ms = eig_ms / launches
-        launch_bytes = solve_bytes / launches
-        achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = measured_traffic(args.config)
-        # the MFMA-bound kernel of the path: symmetric Gram of the E student token matrices (one launch + its
-        # slab reduction per step; the teacher-side call of the same entry point is the shorter of the two)
+        launch_bytes = n_mats * 2 * d_s * d_s * 4          # every matrix read once, its reflectors written once
+        achieved = launch_bytes / (eig_ms * 1e-3) / 1e9 if eig_ms > 0 else 0.0
+        # --- the MFMA-bound kernel: symmetric Gram of the E student token matrices (lower 128x128 tile pairs only)
         tiles = (d_s + 127) // 128
-        syrk = sorted(per_call.get("basd_syrk_multi", [0.0]))
-        syrk = syrk[-args.steps:] if len(syrk) >= args.steps else syrk
-        syrk_ms = sum(syrk) / max(1, len(syrk))
-        syrk_flops = shape.points * (tiles * (tiles + 1) // 2) * 128 * 128 * 2.0 * batch * shape.n_s
+        syrk_ms, _ = longest(["basd_syrk_multi"])
+        syrk_flops = E * (tiles * (tiles + 1) // 2) * 128 * 128 * 2.0 * batch * shape.n_s
         syrk_tf = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+        # --- the HBM stream: column sums of the E student token tensors (every element read once, nothing written)
+        col_ms, _ = longest(["basd_colmean_multi"])
+        col_bytes = ab["student"]
+        col_gbs = col_bytes / (col_ms * 1e-3) / 1e9 if col_ms > 0 else 0.0
         line = {
             "metric": "distillation images/sec (BASD loss fwd+bwd+grad all-reduce), DeiT-S<-ResNet-50 @ bs256/GPU"
-            if args.config == "cfg2" else f"distillation images/sec (BASD loss), {shape.name}",
+            if args.config == "cfg2" else f"distillation images/sec (BASD loss fwd+bwd+grad all-reduce), {shape.name}",
             "value": world * batch * args.steps / elapsed,
             "unit": "images/s",
             "n_gpus": world,
@@ -313,8 +332,9 @@ def main() -> None:
             "loss": float(loss.item()),
             "config": {
                 "workload": shape.name, "per_gpu_batch": batch, "global_batch": world * batch,
-                "student_tokens": [shape.points, batch, shape.n_s, shape.d_s],
-                "teacher_tokens": [shape.layers_t, batch, shape.n_t, shape.d_t],
+                "student_tokens": [E, batch, shape.n_s, d_s],
+                "teacher_tokens": [L, batch, shape.n_t, shape.d_t],
+                "input_dtype": str(inp.student[mod.token_layers[0]].dtype).replace("torch.", ""),
                 "layout": "contiguous" if args.contiguous else "strided (CLS-sliced / channel-major views)",
                 "backward": True,
                 "grad_allreduce_bytes": int(bucket.buffer.numel() * 4),
@@ -330,9 +350,10 @@ def main() -> None:
             },
             "roofline": {
                 "kernel": kernel_name,
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("tridiag_kernel"),
-                "launch_ms": launch_ms, "launches_per_step": launches, "solve_ms_per_step": eig_ms,
+                "bound": "hbm", "regime": "latency", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("tridiag"),
+                "traffic_source": traffic_source if traffic.get("tridiag") else None,
+                "launch_ms": eig_ms, "launches_per_step": eig_calls,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "note": note,
             },
@@ -340,10 +361,20 @@ def main() -> None:
                 "kernel": "syrk_tn_kernel (+ syrk_reduce_kernel): centred Gram matrices of the E student layers",
                 "bound": "mfma", "achieved": syrk_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": syrk_tf / MFMA_F32_PEAK_TF, "traffic": traffic.get("syrk_tn_kernel"),
+                "traffic_source": traffic_source if traffic.get("syrk_tn_kernel") else None,
                 "launch_ms": syrk_ms, "executed_flops_per_launch": syrk_flops,
                 "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32); flops counted are the lower-triangular 128x128 tile "
-                        "pairs actually executed; timed inside the step, i.e. while the teacher chain's kernels "
+                        "pairs actually executed; timed inside the step, i.e. while the other streams' kernels "
                         "share the chip",
+            },
+            "roofline_hbm_stream": {
+                "kernel": "colsum_partial_vec_kernel (+ colsum_final_kernel): column means of the E student layers",
+                "bound": "hbm", "achieved": col_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": col_gbs / HBM_PEAK_GBS, "traffic": traffic.get("colsum_partial_vec_kernel"),
+                "traffic_source": traffic_source if traffic.get("colsum_partial_vec_kernel") else None,
+                "launch_ms": col_ms, "algorithmic_bytes_per_launch": col_bytes,
+                "note": "every student token element read once (strided CLS-sliced views), nothing written back; "
+                        "timed inside the step",
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -620,7 +620,8 @@ class GrassmannianLayerSelector(nn.Module):
         flip[slot] = (idx + 1) % 4
         key = (slot, idx)
         if key not in bufs or bufs[key].numel() != count:
-            bufs[key] = torch.empty((count,), dtype=torch.int32, pin_memory=True)
+            for i in range(4):       # the whole ring at once: a pinned allocation synchronises the device
+                bufs[(slot, i)] = torch.empty((count,), dtype=torch.int32, pin_memory=True)
         return bufs[key]
 
     def _queue_readback(self, tensors: list[torch.Tensor], slot: str):
