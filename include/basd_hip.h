@@ -322,13 +322,7 @@ int basd_cross_entropy(const void* logits, int dtype, long ld, int B, int C, con
                        long pld, float label_smoothing, long ignore_index, float* row_loss, float* dlogits,
                        hipStream_t stream);
 
-/* ---- CU partitions (hipExtStreamCreateWithCUMask) --------------------------------------------------- */
-
-/* A stream confined to CUs [cu_lo, cu_hi) of EVERY XCD (invert = 0) or to all the others (invert != 0); 32 CUs per XCD
- * on MI355X.  The selector's eigen-solve chains (dependent, latency-bound launches of a few workgroups) are queued on
- * such partitions and this library's throughput kernels on the complement, so that neither slows the other down. */
-int basd_stream_create_masked(int cu_lo, int cu_hi, int invert, hipStream_t* out);
-int basd_stream_destroy(hipStream_t stream);
+/* ---- stream ordering helpers ----------------------------------------------------------------------- */
 
 /* Events to order two streams from inside a library call (basd_tridiag_ranked's mid_event): opaque hipEvent_t handles. */
 int basd_event_create(void** out);

@@ -62,8 +62,6 @@ SIGNATURES = {
     "basd_student_grad_multi": [vp, i32, i64, i64, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp,
                                 vp, vp, vp],
     "basd_procrustes_forward_fused": [vp, vp],
-    "basd_stream_create_masked": [i32, i32, i32, vp],
-    "basd_stream_destroy": [vp],
     "basd_resample_tokens": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "basd_resample_tokens_adjoint": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_student_grad": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp],

@@ -263,7 +263,6 @@ class _SingleTeacherTotal(torch.autograd.Function):
                                     need_mix_grad=False, grad_layers=ones if need_bwd else None)
         geo_layers = pc.loss_b.mean(dim=1)
         ctx.unit_grads = pc.dx          # (E, B, N_s, D_s): gradients for a unit upstream gradient, one buffer
-        ctx.consumer = ops.CONSUMER_STREAM         # set when this node runs on a partition stream (BASDLoss.forward)
         # UW-SO (combined.py:78-85) on the detached values
         vals = torch.stack([ce.detach(), geo_layers.mean().to(ce.dtype)])
         inv = 1.0 / vals.clamp(min=torch.finfo(ce.dtype).eps)
@@ -284,8 +283,6 @@ class _SingleTeacherTotal(torch.autograd.Function):
         if ctx.unit_grads is not None:
             scale = gw[1] / ctx.n_students
             scaled = ctx.unit_grads * scale         # ONE launch over all layers (they share the upstream scalar)
-            if ctx.consumer is not None:            # allocated on this (partition) stream, read on the caller's
-                scaled.record_stream(ctx.consumer)
             grads = [scaled[i].to(dt) if ctx.needs_input_grad[5 + i] else None for i, dt in enumerate(ctx.dtypes)]
         zero = None
         if ctx.zero_shape is not None and ctx.needs_input_grad[2]:
@@ -486,7 +483,7 @@ class GrassmannianLayerSelector(nn.Module):
     # ---- distances + mixing weights ------------------------------------------------------
     @torch.no_grad()
     def _spectra_async(self, students: list[torch.Tensor], teachers: list[torch.Tensor],
-                       all_student_vectors: bool = False, student_stream=None, eig_streams=None) -> dict:
+                       all_student_vectors: bool = False, student_stream=None) -> dict:
         """Queue every Gram matrix and eigen-solve of the step; no host sync.
         (layer_selector.py:69-74, :131-138, :86-92)
 
@@ -495,9 +492,7 @@ class GrassmannianLayerSelector(nn.Module):
         Only the backward of multi-layer teachers needs ALL student eigenvectors: those go through Jacobi.
 
         The teacher chain runs on the current stream; with ``student_stream`` the (independent) student chain
-        is queued there, so the latency-bound eigen-solves of the two sides overlap.  ``eig_streams`` = (teacher,
-        student): streams confined to their own CUs (BASDLoss._partition) that take the eigen-solves proper -- the
-        projection / Gram launches before them stay on the full-chip streams."""
+        is queued there, so the latency-bound eigen-solves of the two sides overlap."""
         d_s = self.student_dim
         E, L = len(students), len(teachers)
         dev = students[0].device
@@ -506,7 +501,6 @@ class GrassmannianLayerSelector(nn.Module):
         # works from the leading k and shifted solves (``_distance_backward``)
         stud_jacobi = not tri
         st = dict(E=E, L=L, tri=tri, stud_jacobi=stud_jacobi, student_stream=student_stream)
-        eig_t, eig_s = eig_streams if (eig_streams is not None and tri) else (None, None)
 
         cur = torch.cuda.current_stream()
         projected = None
@@ -535,19 +529,15 @@ class GrassmannianLayerSelector(nn.Module):
                 if stud_jacobi:
                     st["s_stack"], st["s_colnorm"] = s_stack, ops.jacobi_onesided(s_stack, d_s)
                 else:
-                    if eig_s is not None:
-                        eig_s.wait_stream(torch.cuda.current_stream())
-                        s_stack.record_stream(eig_s)
-                    with torch.cuda.stream(eig_s if eig_s is not None else torch.cuda.current_stream()):
-                        s_ts = ops.tridiagonalise(s_stack)
-                        if student_stream is not None:
-                            # status word of this factorisation: read by the host one step later (it never waits
-                            # for the student chain)
-                            st["student_status"] = self._queue_readback([s_ts.err], "student")
-                        elif eig_s is None:
-                            # same stream as the teacher chain that follows: complete when the rank event is
-                            st["student_status_now"] = self._queue_readback([s_ts.err], "student")
-                        ops.tridiag_spectrum(s_ts)
+                    s_ts = ops.tridiagonalise(s_stack)
+                    if student_stream is not None:
+                        # status word of this factorisation: read by the host one step later (it never waits
+                        # for the student chain)
+                        st["student_status"] = self._queue_readback([s_ts.err], "student")
+                    else:
+                        # same stream as the teacher chain that follows: complete when the rank event is
+                        st["student_status_now"] = self._queue_readback([s_ts.err], "student")
+                    ops.tridiag_spectrum(s_ts)
                     st["s_ts"] = s_ts
 
         # Two chains: the student chain is not on the path the host waits for, and its Gram launch (the largest MFMA
@@ -571,27 +561,23 @@ class GrassmannianLayerSelector(nn.Module):
             # The host waits for the ranks and for nothing else: they come straight from the tridiagonals of
             # the uncentred Grams (median by multisection + one Sturm count), are copied to pinned memory at
             # once, and only then are the centred spectra (needed by the eigenvector stage alone) queued.
-            if eig_t is not None:
-                eig_t.wait_stream(cur)
-                t_stack.record_stream(eig_t)
-            with torch.cuda.stream(eig_t if eig_t is not None else cur):
-                # ranks straight out of the factorisation's last kernel                          (:16-19, :74)
-                pin = self._pinned_ints("teacher", L + 8)
-                gate = None
-                if gated:
-                    if getattr(self, "_gate_event", None) is None:
-                        self._gate_event = ops.new_event()
-                    gate = self._gate_event
-                ts = ops.tridiagonalise(t_stack, mp_rank=(M, d_s, d_s - 1, L, pin, gate))
-                st["t_ts"] = ts
-                st["ranks_dev"] = ts.ranks
-                ops.gpu_mark("ranks_ready")
-                ready = torch.cuda.Event(enable_timing=chain_t0 is not None)
-                ready.record()
-                st["rank_ready"] = (pin, ready)
-                if chain_t0 is not None:
-                    ops.CHAIN_EVENTS.append((chain_t0, ready))
-                ops.tridiag_spectrum(ts, first=o_c, count=L)
+            # ranks straight out of the factorisation's last kernel                          (:16-19, :74)
+            pin = self._pinned_ints("teacher", L + 8)
+            gate = None
+            if gated:
+                if getattr(self, "_gate_event", None) is None:
+                    self._gate_event = ops.new_event()
+                gate = self._gate_event
+            ts = ops.tridiagonalise(t_stack, mp_rank=(M, d_s, d_s - 1, L, pin, gate))
+            st["t_ts"] = ts
+            st["ranks_dev"] = ts.ranks
+            ops.gpu_mark("ranks_ready")
+            ready = torch.cuda.Event(enable_timing=chain_t0 is not None)
+            ready.record()
+            st["rank_ready"] = (pin, ready)
+            if chain_t0 is not None:
+                ops.CHAIN_EVENTS.append((chain_t0, ready))
+            ops.tridiag_spectrum(ts, first=o_c, count=L)
             if gated:
                 student_chain(gate)
             return st
@@ -905,37 +891,6 @@ class BASDLoss(nn.Module):
         # (or ``sync_ranks = False``): with one teacher layer the ranks do not feed the loss, the read-back is then
         # completed by the next forward / the first reader of ``subspace_ranks`` and consecutive steps may overlap.
         self.sync_ranks = os.environ.get("BASD_RANK_READBACK", "sync") != "deferred"
-        # CU partition "a,b" (CUs per XCD for the teacher chain / the student chain), "0" = off; see _partition
-        part = [int(v) for v in os.environ.get("BASD_CU_PARTITION", "0").split(",")]
-        self.cu_partition = tuple((part + [0])[:2]) if part[0] > 0 else None
-
-    def _partition(self, device, lane: int = 0):
-        """CU partitions (basd_stream_create_masked): ``cu_partition`` = (a, b) CUs of every XCD for the teacher
-        chain + selector tail and for the student chain; this library's throughput kernels go to the complement.
-        Returns None when switched off, else a dict of torch streams (one set per lane of chain streams)."""
-        if not self.cu_partition:
-            return None
-        key = ("part", str(device), lane)
-        if key not in self._side_streams:
-            import ctypes
-            a, b = self.cu_partition
-            # the workgroups sharing a matrix in the tridiagonalisation's first stage normally sit on ONE XCD (ids
-            # equal mod 8: shared L2); a partition has only a few CUs per XCD, too few for all of them to be resident
-            # -- and they wait for each other.  One id of padding between matrices spreads them over the XCDs.
-            ops._lib.call("basd_tridiag_tuning", -1, 1, -1, -1, -1, 0)
-            with torch.cuda.device(device):
-                def make(lo, hi, invert):
-                    h = ctypes.c_void_p()
-                    ops._lib.call("basd_stream_create_masked", lo, hi, invert, ctypes.byref(h))
-                    return torch.cuda.ExternalStream(h.value, device=device)
-                part = {"eig_t": make(0, a, 0), "tail": make(0, a, 0)}
-                part["eig_s"] = make(a, a + b, 0) if b > 0 else make(0, a, 0)
-                bulk_key = ("bulk", str(device))
-                if bulk_key not in self._side_streams:
-                    self._side_streams[bulk_key] = make(0, a + b, 1)
-                part["bulk"] = self._side_streams[bulk_key]
-            self._side_streams[key] = part
-        return self._side_streams[key]
 
     def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
         key = (str(device), index)
@@ -981,8 +936,6 @@ class BASDLoss(nn.Module):
                 lane = self._chain_lane = (getattr(self, "_chain_lane", 1) + 1) % 2
             side = self._selector_stream(main.device, 3 * lane)
             side2 = self._selector_stream(main.device, 3 * lane + 1)
-            part = self._partition(main.device, lane)
-            eig = (part["eig_t"], part["eig_s"]) if part else None
             side.wait_stream(main)
             # the borrowed inputs are read on the side streams after this call has returned (the tail of the
             # selector is not joined into the main stream: nothing downstream of it feeds the loss)
@@ -990,10 +943,10 @@ class BASDLoss(nn.Module):
                 t.record_stream(side)
                 t.record_stream(side2)
             with torch.cuda.stream(side):
-                spectra = sel._spectra_async(students, teachers, student_stream=side2, eig_streams=eig)
+                spectra = sel._spectra_async(students, teachers, student_stream=side2)
             # what the selector tail of THIS step has to wait for (it may be queued after later steps' chains)
             chain_done = []
-            for st_ in ((eig[0], eig[1]) if part else (side, side2)):
+            for st_ in (side, side2):
                 ev = torch.cuda.Event()
                 ev.record(st_)
                 chain_done.append(ev)
@@ -1001,26 +954,10 @@ class BASDLoss(nn.Module):
             ce_loss = _base_loss(self.base_criterion, student_output, targets)     # behind the chains' first launches
             # softmax over ONE logit: the mixing weights are exactly 1 and d loss / d temperature exactly 0
             mix = ops._device_consts((1.0,) * len(students), torch.float32, main.device).view(-1, 1)
-            if part:
-                # the Procrustes kernels on the complement of the chains' CUs; autograd runs the backward of this
-                # node on the same stream and orders it against the caller's
-                bulk = part["bulk"]
-                bulk.wait_stream(main)
-                ops.CONSUMER_STREAM = main
-                try:
-                    with torch.cuda.stream(bulk):
-                        total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
-                                                                      sel.log_temperatures, teachers, attns, *students)
-                finally:
-                    ops.CONSUMER_STREAM = None
-                main.wait_stream(bulk)
-                total.record_stream(main)
-                geo_layers.record_stream(main)
-            else:
-                total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
-                                                              sel.log_temperatures, teachers, attns, *students)
+            total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
+                                                          sel.log_temperatures, teachers, attns, *students)
             ops.trace("procrustes_queued")
-            tail = part["tail"] if part else self._selector_stream(main.device, 3 * lane + 2)
+            tail = self._selector_stream(main.device, 3 * lane + 2)
 
             def read_ranks():
                 # The host reads the ranks here (and raises on rank 0 like the reference).

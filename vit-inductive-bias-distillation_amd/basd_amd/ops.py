@@ -51,10 +51,6 @@ def _ptr(t: torch.Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
 
-# Stream that will read the outputs of an autograd node running on a CU-partition stream (BASDLoss.forward sets it
-# around the node's forward; the node's backward marks its results as in use there).
-CONSUMER_STREAM = None
-
 # Host-side timeline of a step (tools/host_timeline.py): list of (label, perf_counter) when switched on.
 HOST_TRACE: list | None = None
 CHAIN_EVENTS: list = []          # (start, rank-ready) timing events of the teacher chain while HOST_TRACE is on

@@ -76,33 +76,6 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
 }
 
 
-// ---------------------------------------------------------------------------
-// CU partitions.  The eigen-solve chains of a step are dependent sequences of small, latency-bound launches (a few
-// dozen workgroups that need every wave scheduled at once); the Gram / Procrustes kernels around them are throughput
-// kernels that fill every CU.  Sharing CUs, the chain kernels run 2-10x longer than alone (rocprofv3, cfg-2: rank kernel
-// 0.49 ms inside a step, 0.05 alone) and they are what the host waits for.  A HIP stream can be confined to a set of
-// CUs (hipExtStreamCreateWithCUMask): the chains get a few CUs of every XCD to themselves and the throughput kernels
-// of this library are queued on a stream masked to the complement.
-// Mask bit i enables CU (i / 8) of XCD (i % 8) on MI355X (probe: tools/probe/cumask_probe.hip; every XCD needs at least
-// one enabled CU, an XCD with an empty mask gets all of its CUs).  [cu_lo, cu_hi) = CU range inside each XCD;
-// invert != 0 selects the complement.
-// ---------------------------------------------------------------------------
-int basd_stream_create_masked(int cu_lo, int cu_hi, int invert, hipStream_t* out) {
-    BASD_CHECK_ARG(out && cu_lo >= 0 && cu_hi > cu_lo && cu_hi <= 32);
-    BASD_CHECK_ARG(!(invert && cu_lo == 0 && cu_hi == 32));
-    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int cu = 0; cu < 32; ++cu) {
-        const bool in = cu >= cu_lo && cu < cu_hi;
-        if (in == (invert != 0)) continue;
-        for (int xcd = 0; xcd < 8; ++xcd) {
-            const int bit = cu * 8 + xcd;
-            mask[bit >> 5] |= 1u << (bit & 31);
-        }
-    }
-    hipError_t e = hipExtStreamCreateWithCUMask(out, 8, mask);
-    return e == hipSuccess ? BASD_OK : (int)e;
-}
-
 // Events for ordering two streams from inside a library call (see basd_tridiag_ranked's mid_event).
 int basd_event_create(void** out) {
     BASD_CHECK_ARG(out);
@@ -116,11 +89,6 @@ int basd_event_destroy(void* ev) {
 int basd_stream_wait_event(hipStream_t stream, void* ev) {
     BASD_CHECK_ARG(ev);
     hipError_t e = hipStreamWaitEvent(stream, (hipEvent_t)ev, 0);
-    return e == hipSuccess ? BASD_OK : (int)e;
-}
-
-int basd_stream_destroy(hipStream_t stream) {
-    hipError_t e = hipStreamDestroy(stream);
     return e == hipSuccess ? BASD_OK : (int)e;
 }
 
