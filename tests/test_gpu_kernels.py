@@ -39,7 +39,9 @@ def test_gemm_nt_layouts(dev):
     assert _rel(ops.gemm_nt(big, wb, scale=0.5), 0.5 * big.double() @ wb.double().T) < 2e-6
 
 
-@pytest.mark.parametrize("M,K,N,cm", [(1000, 96, 200, False), (12544 // 4, 2048 // 4, 384, True), (77, 40, 64, False)])
+@pytest.mark.parametrize("M,K,N,cm", [(1000, 96, 200, False), (12544 // 4, 2048 // 4, 384, True), (77, 40, 64, False),
+                                      # many row tiles: the XCD-aware 1-D grid, full and ragged
+                                      (12544, 2048, 384, True), (8192 + 37, 300, 384, False), (9000, 260, 200, False)])
 def test_gemm_nt_column_mean_epilogue(dev, M, K, N, cm):
     """Column means of C from the projection kernel's epilogue (ragged last row tile, channel-major A, bias)."""
     from basd_amd import ops
@@ -54,6 +56,10 @@ def test_gemm_nt_column_mean_epilogue(dev, M, K, N, cm):
     ref = 0.5 * a.double().reshape(-1, K) @ b.double().T - bias.double()
     assert _rel(out, ref) < 2e-6
     assert _rel(mean, ref.mean(0)) < 2e-6
+    if M >= 8192:
+        ab = a.bfloat16()
+        outb = ops.gemm_nt(ab, b, scale=0.5, bias=bias)
+        assert _rel(outb, 0.5 * ab.double().reshape(-1, K) @ b.double().T - bias.double()) < 2e-6
     slot = torch.zeros(3, N, device=dev)
     ops.gemm_nt(a, b, col_mean=True, mean_out=slot[1])
     assert _rel(slot[1], (a.double().reshape(-1, K) @ b.double().T).mean(0)) < 2e-6

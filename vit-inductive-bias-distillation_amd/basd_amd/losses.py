@@ -107,6 +107,19 @@ def _align_token_count(tokens: torch.Tensor, target_n: int) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 # Procrustes loss over all extraction layers (autograd boundary)
 # --------------------------------------------------------------------------- #
+class TridiagGiveUp(RuntimeError):
+    """Workgroups sharing a matrix in the tridiagonalisation's first stage lost each other (bounded spin): the eigen-
+    solve results of this step are invalid.  The callers re-queue the step's selector with ONE workgroup per matrix
+    (nothing waits for anything then) and keep that setting: a slower selector instead of a dead training run."""
+
+
+def _single_member_mode(why: str) -> None:
+    import warnings
+    warnings.warn("basd_tridiag: " + why + "; switching the tridiagonalisation to one workgroup per matrix "
+                  "(no inter-workgroup hand-off; slower first stage) for the rest of this process", RuntimeWarning)
+    ops._lib.call("basd_tridiag_tuning", 1, -1, -1, -1, -1, 0)
+
+
 def _record_stream(obj, stream) -> None:
     """Mark every tensor reachable from a (nested) state object as in use on `stream`."""
     if isinstance(obj, torch.Tensor):
@@ -299,8 +312,14 @@ class _GrassmannDistance(torch.autograd.Function):
     @staticmethod
     def forward(ctx, selector, keys, teachers, *students):
         want_grad = any(s.requires_grad for s in students)
-        spectra = selector._spectra_async(list(students), teachers, all_student_vectors=want_grad)
-        d, saved = selector._angles_from_spectra(spectra, keys, want_grad=want_grad)
+        try:
+            spectra = selector._spectra_async(list(students), teachers, all_student_vectors=want_grad)
+            d, saved = selector._angles_from_spectra(spectra, keys, want_grad=want_grad)
+        except TridiagGiveUp as exc:       # degrade, do not die: once more with one workgroup per matrix
+            _single_member_mode(str(exc))
+            torch.cuda.synchronize(students[0].device)
+            spectra = selector._spectra_async(list(students), teachers, all_student_vectors=want_grad)
+            d, saved = selector._angles_from_spectra(spectra, keys, want_grad=want_grad)
         ctx.saved = saved
         ctx.selector = selector
         ctx.n_students = len(students)
@@ -434,7 +453,8 @@ class GrassmannianLayerSelector(nn.Module):
         column means of z (:35) from them, so no separate reduction sits on the teacher chain."""
         d_s, L = self.student_dim, len(teachers)
         M = teachers[0].shape[0] * teachers[0].shape[1]
-        sums = torch.empty((L, (M + 127) // 128, d_s), device=teachers[0].device, dtype=torch.float32)
+        tiles = ops.gemm_nt_row_tiles(M, d_s, teachers[0].shape[2])
+        sums = torch.empty((L, tiles, d_s), device=teachers[0].device, dtype=torch.float32)
         proj_t = self.proj_t.float().contiguous()
         zs = [ops.gemm_nt(ops.as_supported(t), proj_t, col_sums=sums[l]) for l, t in enumerate(teachers)]
         return zs, sums
@@ -633,7 +653,10 @@ class GrassmannianLayerSelector(nn.Module):
             pending = self.__dict__.pop("_pending_status", None)
             if pending is not None:                # student chain of the PREVIOUS step: long complete
                 pending[1].synchronize()
-                status.append(int(pending[0][0]))
+                if int(pending[0][0]):
+                    # its eigenvectors only fed that step's principal angles, which nothing observed (one teacher
+                    # layer): nothing to redo, but do not let it happen again
+                    _single_member_mode("the student-side factorisation of the previous step timed out")
             if "student_status" in st:
                 self._pending_status = st["student_status"]
             if "student_status_now" in st:         # multi-layer teachers: the student eigenvectors feed this loss
@@ -646,8 +669,8 @@ class GrassmannianLayerSelector(nn.Module):
         ops.trace("ranks_read")
         ranks = [int(r) for r in host[:L]]
         if any(status):
-            raise RuntimeError("basd_tridiag: workgroups sharing a matrix timed out waiting for each other "
-                               f"(device oversubscribed?); eigen-solve results are invalid [{host[L:]}]")
+            raise TridiagGiveUp("basd_tridiag: workgroups sharing a matrix timed out waiting for each other "
+                                f"(device oversubscribed?); eigen-solve results are invalid [{host[L:]}]")
         for k, r in zip(keys, ranks):
             self._subspace_ranks[k] = r
         if min(ranks) == 0:
@@ -959,13 +982,30 @@ class BASDLoss(nn.Module):
             ops.trace("procrustes_queued")
             tail = self._selector_stream(main.device, 3 * lane + 2)
 
-            def read_ranks():
+            def read_ranks_once():
                 # The host reads the ranks here (and raises on rank 0 like the reference).
                 if "rank_ready" in spectra:
                     return sel._read_ranks(spectra, keys)               # waits on the rank kernel's event
                 with torch.cuda.stream(side):                           # plain read-back behind both chains
                     side.wait_stream(side2)
                     return sel._read_ranks(spectra, keys)
+
+            def read_ranks():
+                nonlocal spectra, chain_done
+                try:
+                    return read_ranks_once()
+                except TridiagGiveUp as exc:
+                    # degrade, do not die: the selector of THIS step once more, one workgroup per matrix
+                    _single_member_mode(str(exc))
+                    torch.cuda.synchronize(main.device)
+                    with torch.cuda.stream(side):
+                        spectra = sel._spectra_async(students, teachers, student_stream=side2)
+                    chain_done = []
+                    for st_ in (side, side2):
+                        ev = torch.cuda.Event()
+                        ev.record(st_)
+                        chain_done.append(ev)
+                    return read_ranks_once()
 
             def queue_tail(ranks, gate_tail=False):
                 # The rest of the selector (eigenvectors, principal angles) goes to a third stream: the next step's

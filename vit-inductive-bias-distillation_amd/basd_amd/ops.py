@@ -100,17 +100,23 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, scale: float = 1.0, out: torch.
     if out is None:
         out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=a.device, dtype=torch.float32)
     part = mean = None
+    tiles = gemm_nt_row_tiles(M, N, K, batch, beta)
     if col_sums is not None:            # row-tile column sums only (folded later, e.g. inside centered_grams)
-        assert col_sums.is_contiguous() and col_sums.numel() == batch * ((M + 127) // 128) * N
+        assert col_sums.is_contiguous() and col_sums.numel() == batch * tiles * N
         part = col_sums
     if col_mean:
-        part = torch.empty((batch, (M + 127) // 128, N), device=a.device, dtype=torch.float32)
+        part = torch.empty((batch, tiles, N), device=a.device, dtype=torch.float32)
         mean = mean_out if mean_out is not None else \
             torch.empty((batch, N) if batch > 1 else (N,), device=a.device, dtype=torch.float32)
         assert mean.dtype == torch.float32 and mean.is_contiguous() and mean.numel() == batch * N
     _lib.call("basd_gemm_nt", ptr, dt, sb, sn, sd, rpb, a_batch_stride, b.data_ptr(), ldb, b_batch_stride,
               M, N, K, batch, out.data_ptr(), N, M * N, scale, _ptr(bias), beta, _ptr(part), _ptr(mean), _stream())
     return (out, mean) if col_mean else out
+
+
+def gemm_nt_row_tiles(M: int, N: int, K: int, batch: int = 1, beta: float = 0.0) -> int:
+    """Number of row tiles ``gemm_nt`` leaves column sums for (128-row tiles)."""
+    return (M + 127) // 128
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, mean_a: torch.Tensor | None = None,
