@@ -503,7 +503,7 @@ class GrassmannianLayerSelector(nn.Module):
     # ---- distances + mixing weights ------------------------------------------------------
     @torch.no_grad()
     def _spectra_async(self, students: list[torch.Tensor], teachers: list[torch.Tensor],
-                       all_student_vectors: bool = False, student_stream=None) -> dict:
+                       all_student_vectors: bool = False, student_stream=None, defer_student: bool = False) -> dict:
         """Queue every Gram matrix and eigen-solve of the step; no host sync.
         (layer_selector.py:69-74, :131-138, :86-92)
 
@@ -512,7 +512,9 @@ class GrassmannianLayerSelector(nn.Module):
         Only the backward of multi-layer teachers needs ALL student eigenvectors: those go through Jacobi.
 
         The teacher chain runs on the current stream; with ``student_stream`` the (independent) student chain
-        is queued there, so the latency-bound eigen-solves of the two sides overlap."""
+        is queued there, so the latency-bound eigen-solves of the two sides overlap.  ``defer_student``: when the student
+        chain is gated behind the teacher's first tridiagonalisation stage anyway, leave its queueing to the caller
+        (``st["queue_student"]()``): the host can queue the Procrustes kernels first."""
         d_s = self.student_dim
         E, L = len(students), len(teachers)
         dev = students[0].device
@@ -598,7 +600,9 @@ class GrassmannianLayerSelector(nn.Module):
             if chain_t0 is not None:
                 ops.CHAIN_EVENTS.append((chain_t0, ready))
             ops.tridiag_spectrum(ts, first=o_c, count=L)
-            if gated:
+            if gated and defer_student:
+                st["queue_student"] = lambda: student_chain(gate)
+            elif gated:
                 student_chain(gate)
             return st
         if gated:
@@ -966,13 +970,7 @@ class BASDLoss(nn.Module):
                 t.record_stream(side)
                 t.record_stream(side2)
             with torch.cuda.stream(side):
-                spectra = sel._spectra_async(students, teachers, student_stream=side2)
-            # what the selector tail of THIS step has to wait for (it may be queued after later steps' chains)
-            chain_done = []
-            for st_ in (side, side2):
-                ev = torch.cuda.Event()
-                ev.record(st_)
-                chain_done.append(ev)
+                spectra = sel._spectra_async(students, teachers, student_stream=side2, defer_student=True)
             ops.trace("chains_queued")
             ce_loss = _base_loss(self.base_criterion, student_output, targets)     # behind the chains' first launches
             # softmax over ONE logit: the mixing weights are exactly 1 and d loss / d temperature exactly 0
@@ -980,6 +978,18 @@ class BASDLoss(nn.Module):
             total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
                                                           sel.log_temperatures, teachers, attns, *students)
             ops.trace("procrustes_queued")
+            # the student chain waits for the teacher's first tridiagonalisation stage on the GPU anyway: queue it now,
+            # behind the Procrustes kernels, instead of in front of them
+            queue_student = spectra.pop("queue_student", None)
+            if queue_student is not None:
+                with torch.cuda.stream(side):
+                    queue_student()
+            # what the selector tail of THIS step has to wait for (it may be queued after later steps' chains)
+            chain_done = []
+            for st_ in (side, side2):
+                ev = torch.cuda.Event()
+                ev.record(st_)
+                chain_done.append(ev)
             tail = self._selector_stream(main.device, 3 * lane + 2)
 
             def read_ranks_once():
