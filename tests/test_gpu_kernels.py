@@ -249,14 +249,16 @@ def test_tridiag_member_count_is_invisible(dev, n, tuning):
     assert ((outs[-1].vals.double().cpu() - ref).abs().max(dim=1).values / ref[:, 0]).max() < 3e-6
 
 
-@pytest.mark.parametrize("n", [384, 256, 257, 300, 192, 768, 64, 7])
-def test_tridiag_tail_stage_reconstructs_the_matrix(dev, n, tuning):
+@pytest.mark.parametrize("tail", [1, 2])
+@pytest.mark.parametrize("n", [384, 256, 257, 300, 192, 768, 64, 7, 2])
+def test_tridiag_tail_stage_reconstructs_the_matrix(dev, n, tail, tuning):
     """The register-resident tail stage (whole factorisation for n <= 256, last 256 steps above): Q T Q^T gives the
     matrix back, Q is orthogonal, and T has the spectrum of the all-shared-stage factorisation."""
     from basd_amd import ops
     g = torch.Generator().manual_seed(31 * n)
     x = torch.randn(3, 3 * n + 5, n, generator=g)
     G0 = (x.transpose(1, 2) @ x).to(dev)
+    tuning(tail=tail)                   # 1: two-barrier form (default), 2: four-barrier form
     ts = ops.tridiag_eigenvalues(G0.clone())
     assert int(ts.err[0].item()) == 0
     eye = torch.eye(n, device=dev).repeat(3, 1, 1).contiguous()

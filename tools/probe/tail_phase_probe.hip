@@ -1,0 +1,42 @@
+// Where a step of the register-resident tail stage goes: s_memtime stamps of wave 0 and the last wave at the phase
+// boundaries of every step (BASD_TAIL_DBG build of tridiag.hip), n = 256, one matrix.
+#define BASD_TAIL_DBG 1
+#include "../../vit-inductive-bias-distillation_amd/csrc/tridiag.hip"
+#include <stdio.h>
+#include <vector>
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 256, tailmode = argc > 2 ? atoi(argv[2]) : 1;
+    std::vector<float> h((size_t)n * n);
+    srand(1);
+    std::vector<float> x((size_t)n * n);
+    for (auto& v : x) v = (float)rand() / RAND_MAX - 0.5f;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { float s = 0; for (int k = 0; k < n; ++k) s += x[(size_t)i * n + k] * x[(size_t)j * n + k]; h[(size_t)i * n + j] = s; }
+    float *a, *d, *e, *tau, *vh; void* work;
+    hipMalloc(&a, sizeof(float) * n * n); hipMalloc(&d, 4 * n); hipMalloc(&e, 4 * n); hipMalloc(&tau, 4 * n);
+    hipMalloc(&vh, sizeof(float) * n * n); hipMalloc(&work, basd_tridiag_workspace_bytes(n, 1));
+    basd_tridiag_tuning(-1, -1, -1, -1, tailmode, 0);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipMemcpy(a, h.data(), sizeof(float) * n * n, hipMemcpyHostToDevice);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        int rc = basd_tridiag(a, (long)n * n, n, 1, d, e, tau, vh, work, 0);
+        hipEventRecord(e1); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("rc %d  %.3f ms\n", rc, ms);
+    }
+    std::vector<long long> t(8 * 2 * 1024);
+    hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(basd::g_tail_dbg), sizeof(long long) * 8 * 2 * 1024);
+    const char* names[] = {"pass", "A-wait", "sum", "scalar", "reflector", "B-wait"};
+    for (int jl : {2, 64, 128, 200, 250}) {
+        if (jl >= n - 2) continue;
+        for (int w = 0; w < 2; ++w) {
+            printf("step %3d wave %s:", jl, w ? "last" : "0   ");
+            for (int sl = 0; sl < 6; ++sl) printf(" %s %lld", names[sl], t[(jl * 8 + sl + 1) * 2 + w] - t[(jl * 8 + sl) * 2 + w]);
+            printf(" | next-step start after %lld\n", t[((jl + 1) * 8) * 2 + w] - t[(jl * 8) * 2 + w]);
+        }
+    }
+    std::vector<float> hd(n); hipMemcpy(hd.data(), d, 4 * n, hipMemcpyDeviceToHost);
+    double tr = 0, tr0 = 0; for (int i = 0; i < n; ++i) { tr += hd[i]; tr0 += h[(size_t)i * n + i]; }
+    printf("trace %.6f vs %.6f\n", tr, tr0);
+    return 0;
+}

@@ -10,7 +10,7 @@ for n, batch in [(384, 2), (384, 6), (768, 28), (192, 6)]:
     g = torch.Generator().manual_seed(n)
     x = torch.randn(batch, 4 * n, n, generator=g)
     G0 = (x.transpose(1, 2) @ x).to(dev)
-    for tail in (0, 1, 2):
+    for tail in (1, 2):
         _lib.call("basd_tridiag_tuning", -1, -1, -1, -1, tail, 1)
         copies = [G0.clone() for _ in range(12)]
         for c in copies[:2]:

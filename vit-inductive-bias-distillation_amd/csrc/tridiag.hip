@@ -547,6 +547,357 @@ __global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restr
 }
 
 // ---------------------------------------------------------------------------
+// tridiag_tail_kernel, second form (8 waves).  What limits a step of the first form is not the barriers (~100 cycles
+// each) but INSTRUCTION ISSUE and the LDS return path: a SIMD issues one wave64 VALU instruction per 4 cycles, the waves
+// of a SIMD share it, and s_memtime stamps (tools/probe/tail_phase_probe.hip) put the pass at 1500-2300 cycles and the
+// scalar part of the step -- which the threads < m of four waves ran between four barriers -- at ~3000.  Per matrix row
+// the first form issues 8 packed FMAs, 10 v_mov that splat (u_r, v_r, w_r) into register pairs, and a uniform branch.
+// Here
+//   * rows are consumed in pairs (r_a = wave + 16 P, r_b = r_a + 8); per wave and pair LDS holds (v_a, w_a, v_b, w_b)
+//     and (u_a, u_b), fetched two pairs ahead with one b128 + one b64 read, and a wave-uniform operand of a packed FMA is
+//     taken from either half of a register pair with op_sel / op_sel_hi: a pair of rows is 12 v_pk_fma_f32 and nothing
+//     else -- no splat by the VALU, no splat by LDS (that form was bound by the LDS return path);
+//   * the pass is entered at its first live pair through a jump table (rows below r0 are finished: the live pairs are a
+//     suffix) and the pivot row is copied out by a second one: two indirect jumps instead of ~70 uniform branches;
+//   * lane l of a wave owns the columns c_k = (l & 7) + 32 (l >> 3) + 8 k, k < 4:
+//     exactly the rows of pairs 2 (l >> 3), 2 (l >> 3) + 1 of wave l & 7, so the column form of u, v, w IS the row
+//     operand table -- wave 0 publishes a step with three ds_write_b128 per lane;
+//   * the scalar part of the step (partials -> p, gamma, w, the next pivot row, its norm, the next reflector) is ONE
+//     wave's dependent chain: wave 0 keeps u in column form in registers, uses wave-level sums only and branch-free
+//     selects, and is alone on its SIMD meanwhile (the others wait at barrier B) -- its instructions cost latency, not
+//     the issue slots of every wave; d, e, tau collect in LDS and are stored once at the end; the reflector row is
+//     stored by the LAST wave behind barrier B;
+//   * two workgroup barriers per step: A publishes the partials and the captured row, B the operands of the next pass.
+// Same arithmetic as the first form (same update order, same reflector formulas).
+// ---------------------------------------------------------------------------
+#ifdef BASD_TAIL_DBG
+__device__ long long g_tail_dbg[8 * 2 * 1024];
+#define TAIL_STAMP(slot) do { if (z == 0 && lane == 0 && (wave == 0 || wave == WAVES - 1)) g_tail_dbg[(jl * 8 + (slot)) * 2 + (wave != 0)] = clock64(); } while (0)
+#else
+#define TAIL_STAMP(slot) do { } while (0)
+#endif
+typedef float tri_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lane_bcast(float x, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+// x[q] of four wave-uniform values by a wave-uniform q in 0..3: scalar selects (hipcc turns the C form into branches)
+__device__ __forceinline__ float uniform_select4(float t0, float t1, float t2, float t3, int q) {
+    int r;
+    asm("s_cmp_eq_u32 %5, 1\n\t"
+        "s_cselect_b32 %0, %2, %1\n\t"
+        "s_cmp_eq_u32 %5, 2\n\t"
+        "s_cselect_b32 %0, %3, %0\n\t"
+        "s_cmp_eq_u32 %5, 3\n\t"
+        "s_cselect_b32 %0, %4, %0"
+        : "=&s"(r)
+        : "s"(__float_as_int(t0)), "s"(__float_as_int(t1)), "s"(__float_as_int(t2)), "s"(__float_as_int(t3)), "s"(q)
+        : "scc");
+    return __int_as_float(r);
+}
+// eight b128 rows, 1 KB apart, in flight together (hipcc serialises them: read, wait, add, read ...)
+__device__ __forceinline__ void lds_read8_b128(unsigned addr, tri_f32x4 (&x)[8]) {
+    asm volatile(
+        "ds_read_b128 %0, %8\n\t"
+        "ds_read_b128 %1, %8 offset:1024\n\t"
+        "ds_read_b128 %2, %8 offset:2048\n\t"
+        "ds_read_b128 %3, %8 offset:3072\n\t"
+        "ds_read_b128 %4, %8 offset:4096\n\t"
+        "ds_read_b128 %5, %8 offset:5120\n\t"
+        "ds_read_b128 %6, %8 offset:6144\n\t"
+        "ds_read_b128 %7, %8 offset:7168\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+        : "v"(addr)
+        : "memory");
+}
+__device__ __forceinline__ void pkfma_lo(tri_f2& a, tri_f2 p, tri_f2 b) {      // a += p.x * b
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a) : "v"(p), "v"(b));
+}
+__device__ __forceinline__ void pkfma_hi(tri_f2& a, tri_f2 p, tri_f2 b) {      // a += p.y * b
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(p), "v"(b));
+}
+template <int P>
+__device__ __forceinline__ void lds_pair_issue(unsigned bvw, unsigned bu2, tri_f32x4& vw, tri_f2& u2) {
+    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%5"
+                 : "=&v"(vw), "=&v"(u2) : "v"(bvw), "v"(bu2), "n"(16 * P), "n"(8 * P) : "memory");
+}
+// the registers only hold the pair's operands behind this wait; NEWER = LDS reads issued after them
+template <int NEWER>
+__device__ __forceinline__ void lds_pair_wait(tri_f32x4& vw, tri_f2& u2) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vw), "+v"(u2) : "n"(NEWER) : "memory");
+}
+// rows r_a, r_b of one pair:  a' = a - w_r v_c - v_r w_c ;  acc_c += a' u_r   (nvc = -v_c, nwc = -w_c)
+__device__ __forceinline__ void tail_pair_update(tri_f2 (&ra)[2], tri_f2 (&rb)[2], tri_f32x4 vw, tri_f2 u2,
+                                                 const tri_f2 (&nvc)[2], const tri_f2 (&nwc)[2], tri_f2 (&acc)[2]) {
+    const tri_f2 pa = {vw.x, vw.y}, pb = {vw.z, vw.w};         // (v_a, w_a), (v_b, w_b)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pkfma_hi(ra[q], pa, nvc[q]);
+        pkfma_hi(rb[q], pb, nvc[q]);
+        pkfma_lo(ra[q], pa, nwc[q]);
+        pkfma_lo(rb[q], pb, nwc[q]);
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[q]) : "v"(ra[q]), "v"(u2));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc[q]) : "v"(rb[q]), "v"(u2));
+    }
+}
+
+#define TAIL_PAIR(P)                                                                                              \
+    case P: {                                                                                                     \
+        if ((P) + DIST < NP) lds_pair_issue<(P) + DIST>(bvw, bu2, vw[((P) + DIST) % NBUF], u2[((P) + DIST) % NBUF]); \
+        lds_pair_wait<2 * ((P) + DIST < NP ? DIST : NP - 1 - (P))>(vw[(P) % NBUF], u2[(P) % NBUF]);               \
+        tail_pair_update(a[2 * (P)], a[2 * (P) + 1], vw[(P) % NBUF], u2[(P) % NBUF], nvc, nwc, acc);              \
+    }                                                                                                             \
+    [[fallthrough]];
+#define TAIL_CAP(I)                                                                                               \
+    case I:                                                                                                       \
+        cap4[lane] = tri_f32x4{a[I][0].x, a[I][0].y, a[I][1].x, a[I][1].y};                                       \
+        break;
+
+__global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ A, long a_batch_stride, int n, int j0,
+                                                            const float* __restrict__ pend, float* __restrict__ d,
+                                                            float* __restrict__ e, float* __restrict__ tau_out,
+                                                            float* __restrict__ Vh, MpRankOut rk) {
+    // 8 waves: two per SIMD (a 16-wave variant of this form was no faster and needs more than its 128 VGPRs)
+    constexpr int WAVES = 8, LW = 3, CPL = 4, MMAX = 64 * CPL, RPW = MMAX / WAVES, NP = RPW / 2;   // row r = wave + WAVES i
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ tri_f32x4 op_vw[WAVES][NP];        // (v_a, w_a, v_b, w_b) of the wave's pair P: rows wave + 2 WAVES P, + WAVES
+    __shared__ __attribute__((aligned(16))) tri_f2 op_u[WAVES][NP];   // (u_a, u_b)
+    __shared__ tri_f32x4 part4[WAVES][64];        // per-wave column partials of the lane's four columns
+    __shared__ tri_f32x4 cap4[64];                // the captured pivot row
+    __shared__ float dloc[MMAX], eloc[MMAX], tloc[MMAX];
+    const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = n - j0;
+    float* Az = A + (long)z * a_batch_stride;
+    float* dz = d + (long)z * n;
+    float* ez = e + (long)z * n;
+    float* tz = tau_out + (long)z * n;
+    float* Vz = Vh + (long)z * n * n;
+    const float* pz = pend ? pend + (long)z * 2 * n : nullptr;
+    const int cbase = (lane & (WAVES - 1)) + 4 * WAVES * (lane >> LW);    // column of k = 0; k -> + WAVES k
+    auto col_of = [&](int k) { return cbase + WAVES * k; };
+
+    // ---- the trailing block (pending update of the shared stage applied), zero padded to MMAX
+    tri_f2 a[RPW][2];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave + WAVES * i;
+        const float vr = (pz && r < m) ? pz[j0 + r] : 0.f, wr = (pz && r < m) ? pz[n + j0 + r] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int c = col_of(k);
+            float x = 0.f;
+            if (r < m && c < m) {
+                x = Az[(long)(j0 + r) * n + j0 + c];
+                if (pz) x -= fmaf(vr, pz[n + j0 + c], wr * pz[j0 + c]);
+            }
+            a[i][k >> 1][k & 1] = x;
+        }
+    }
+    // the part of the reflector rows left of the block is zero for every local step: written once, here
+    for (int idx = tid; idx < m * j0; idx += 64 * WAVES) {
+        const int r = idx / j0, c = idx - r * j0;
+        Vz[(long)(j0 + r) * n + c] = 0.f;
+    }
+    const unsigned bvw = (unsigned)(uintptr_t)&op_vw[wave][0], bu2 = (unsigned)(uintptr_t)&op_u[wave][0];
+    // where this lane's columns sit in the operand tables (as rows): wave lane % WAVES, pairs 2 (lane / WAVES) and + 1
+    tri_f32x4* const my_vw = &op_vw[lane & (WAVES - 1)][2 * (lane >> LW)];
+    tri_f32x4* const my_u = (tri_f32x4*)&op_u[lane & (WAVES - 1)][2 * (lane >> LW)];
+
+    // column-form state of wave 0
+    float uc[CPL], cn[CPL], wn[CPL];
+    float tau = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) uc[k] = cn[k] = wn[k] = 0.f;
+    // column-form entry c, broadcast (c wave-uniform); branch-free: four readlanes and scalar selects
+    auto pick = [&](const float (&x)[CPL], int c) {
+        const int l = ((c & (WAVES - 1)) + WAVES * (c >> (LW + 2))) & 63, q = (c >> LW) & 3;
+        const float t0 = lane_bcast(x[0], l), t1 = lane_bcast(x[1], l), t2 = lane_bcast(x[2], l), t3 = lane_bcast(x[3], l);
+        return uniform_select4(t0, t1, t2, t3, q);
+    };
+    // wave 0: reflector of local step jl from cn[] (row jl of the current block); publishes u, v (= the old u), w
+    auto next_reflector = [&](int jl, bool last) {
+        const int r0 = jl + 1;
+        float part2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)        // column c_k = cbase + WAVES k against r0: the uniform side carries the k
+            part2 = cbase > r0 - WAVES * k ? fmaf(cn[k], cn[k], part2) : part2;
+        const float xn2 = wave_sum(part2);
+        const float dnew = pick(cn, jl), alpha = pick(cn, r0);
+        const bool live = !last && xn2 > 0.f;
+        const float beta = live ? -copysignf(__builtin_amdgcn_sqrtf(fmaf(alpha, alpha, xn2)), alpha) : (last ? 0.f : alpha);
+        tau = live ? (beta - alpha) * __builtin_amdgcn_rcpf(beta) : 0.f;
+        const float scal = live ? __builtin_amdgcn_rcpf(alpha - beta) : 0.f;
+        float vo[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int rk = r0 - WAVES * k;
+            vo[k] = uc[k];
+            uc[k] = last ? 0.f : (cbase < rk ? 0.f : (cbase == rk ? 1.f : cn[k] * scal));
+        }
+        my_vw[0] = tri_f32x4{vo[0], wn[0], vo[1], wn[1]};
+        my_vw[1] = tri_f32x4{vo[2], wn[2], vo[3], wn[3]};
+        my_u[0] = tri_f32x4{uc[0], uc[1], uc[2], uc[3]};
+        if (lane == 0) {
+            dloc[jl] = dnew;
+            eloc[jl] = beta;
+            tloc[jl] = tau;
+        }
+    };
+    // the LAST wave, behind barrier B: reflector row of local step jl from the published u
+    auto store_reflector = [&](int jl) {
+        float* vrow = Vz + (long)(j0 + jl) * n + j0;
+        const tri_f32x4 u4 = my_u[0];
+        if (cbase + 0 < m) vrow[cbase + 0] = u4.x;
+        if (cbase + WAVES < m) vrow[cbase + WAVES] = u4.y;
+        if (cbase + 2 * WAVES < m) vrow[cbase + 2 * WAVES] = u4.z;
+        if (cbase + 3 * WAVES < m) vrow[cbase + 3 * WAVES] = u4.w;
+    };
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) cn[k] = a[0][k >> 1][k & 1];
+        next_reflector(0, m <= 1);
+    }
+    lds_barrier();
+    if (wave == WAVES - 1) store_reflector(0);
+
+    for (int jl = 0; jl < m - 1; ++jl) {
+        const int r0 = jl + 1;
+        // ---- pass over the registers
+        TAIL_STAMP(0);
+        tri_f2 nvc[2], nwc[2], acc[2];
+        {
+            const tri_f32x4 o0 = my_vw[0], o1 = my_vw[1];
+            nvc[0] = tri_f2{-o0.x, -o0.z}; nvc[1] = tri_f2{-o1.x, -o1.z};
+            nwc[0] = tri_f2{-o0.y, -o0.w}; nwc[1] = tri_f2{-o1.y, -o1.w};
+            acc[0] = acc[1] = tri_f2{0.f, 0.f};
+        }
+        {
+            // first pair with a live row: rows wave + 2 WAVES P and + WAVES against r0
+            const int p0 = r0 > wave + WAVES ? (r0 - wave - WAVES + 2 * WAVES - 1) >> (LW + 1) : 0;
+            // operands in flight two pairs ahead: with two waves per SIMD one pair of FMAs does not cover an LDS round trip
+            constexpr int DIST = 2, NBUF = DIST + 1;
+            tri_f32x4 vw[NBUF];
+            tri_f2 u2[NBUF];
+            if (p0 < NP) {
+                const int p1 = p0 + 1 < NP ? p0 + 1 : p0;
+                const unsigned a0 = bvw + 16 * p0, b0 = bu2 + 8 * p0, a1 = bvw + 16 * p1, b1 = bu2 + 8 * p1;
+                switch (p0 % 3) {
+                    case 0: lds_pair_issue<0>(a0, b0, vw[0], u2[0]); lds_pair_issue<0>(a1, b1, vw[1], u2[1]); break;
+                    case 1: lds_pair_issue<0>(a0, b0, vw[1], u2[1]); lds_pair_issue<0>(a1, b1, vw[2], u2[2]); break;
+                    default: lds_pair_issue<0>(a0, b0, vw[2], u2[2]); lds_pair_issue<0>(a1, b1, vw[0], u2[0]); break;
+                }
+            }
+            switch (p0) {
+                TAIL_PAIR(0)
+                TAIL_PAIR(1)
+                TAIL_PAIR(2)
+                TAIL_PAIR(3)
+                TAIL_PAIR(4)
+                TAIL_PAIR(5)
+                TAIL_PAIR(6)
+                TAIL_PAIR(7)
+                TAIL_PAIR(8)
+                TAIL_PAIR(9)
+                TAIL_PAIR(10)
+                TAIL_PAIR(11)
+                TAIL_PAIR(12)
+                TAIL_PAIR(13)
+                TAIL_PAIR(14)
+                TAIL_PAIR(15)
+                default: break;
+            }
+        }
+        if (wave == (r0 & (WAVES - 1))) {
+            switch (r0 >> LW) {
+                TAIL_CAP(0)
+                TAIL_CAP(1)
+                TAIL_CAP(2)
+                TAIL_CAP(3)
+                TAIL_CAP(4)
+                TAIL_CAP(5)
+                TAIL_CAP(6)
+                TAIL_CAP(7)
+                TAIL_CAP(8)
+                TAIL_CAP(9)
+                TAIL_CAP(10)
+                TAIL_CAP(11)
+                TAIL_CAP(12)
+                TAIL_CAP(13)
+                TAIL_CAP(14)
+                TAIL_CAP(15)
+                TAIL_CAP(16)
+                TAIL_CAP(17)
+                TAIL_CAP(18)
+                TAIL_CAP(19)
+                TAIL_CAP(20)
+                TAIL_CAP(21)
+                TAIL_CAP(22)
+                TAIL_CAP(23)
+                TAIL_CAP(24)
+                TAIL_CAP(25)
+                TAIL_CAP(26)
+                TAIL_CAP(27)
+                TAIL_CAP(28)
+                TAIL_CAP(29)
+                TAIL_CAP(30)
+                TAIL_CAP(31)
+                default: break;
+            }
+        }
+        part4[wave][lane] = tri_f32x4{acc[0].x, acc[0].y, acc[1].x, acc[1].y};
+        TAIL_STAMP(1);
+        lds_barrier();                                                                     // A
+        TAIL_STAMP(2);
+        if (wave == 0) {
+            // ---- the scalar part of the step: one wave, wave-level sums only
+            tri_f32x4 x8[8];
+            lds_read8_b128((unsigned)(uintptr_t)&part4[0][lane], x8);
+            const tri_f32x4 s4 = ((x8[0] + x8[1]) + (x8[2] + x8[3])) + ((x8[4] + x8[5]) + (x8[6] + x8[7]));
+            float pc[CPL], capc[CPL];
+            const tri_f32x4 c4 = cap4[lane];
+            pc[0] = tau * s4.x; pc[1] = tau * s4.y; pc[2] = tau * s4.z; pc[3] = tau * s4.w;
+            capc[0] = c4.x; capc[1] = c4.y; capc[2] = c4.z; capc[3] = c4.w;
+            TAIL_STAMP(3);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) dot = fmaf(pc[k], uc[k], dot);
+            const float gamma = -0.5f * tau * wave_sum(dot);
+            const float w0 = pick(pc, r0) + gamma;             // u[r0] = 1
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const bool on = cbase >= r0 - WAVES * k;         // column c_k >= r0
+                wn[k] = on ? fmaf(gamma, uc[k], pc[k]) : 0.f;
+                cn[k] = on ? capc[k] - fmaf(uc[k], w0, wn[k]) : 0.f;
+            }
+            TAIL_STAMP(4);
+            next_reflector(jl + 1, jl + 1 >= m - 1);
+            TAIL_STAMP(5);
+        }
+        lds_barrier();                                                                     // B
+        TAIL_STAMP(6);
+        if (wave == WAVES - 1) store_reflector(jl + 1);
+    }
+    lds_barrier();
+    for (int c = tid; c < m; c += 64 * WAVES) {
+        dz[j0 + c] = dloc[c];
+        ez[j0 + c] = eloc[c];
+        tz[j0 + c] = tloc[c];
+    }
+    if (rk.rank_out && z < rk.count && 2 * n <= WAVES * 256) {
+        float* dl = (float*)&part4[0][0];
+        float* el = dl + n;
+        for (int c = tid; c < n; c += 64 * WAVES) {
+            dl[c] = c < j0 ? dz[c] : dloc[c - j0];
+            el[c] = c < j0 ? ez[c] : eloc[c - j0];
+        }
+        __syncthreads();
+        mp_rank_block(dl, el, n, z, rk, nullptr);
+    }
+}
+#undef TAIL_PAIR
+#undef TAIL_CAP
+// ---------------------------------------------------------------------------
 // All eigenvalues of the symmetric tridiagonal (d, e) from Sturm counts (LAPACK sstebz), descending.
 // A Sturm count is a chain of n dependent steps, so plain bisection costs ~45 chains per eigenvalue; here
 // every eigenvalue is owned by one DPP row of 16 lanes that evaluates 16 interior points of its bracket per
@@ -1086,7 +1437,8 @@ constexpr int TRI_TAIL_MAX = 256;      // order of the register-resident trailin
 //   BASD_TRIDIAG_PAD      workgroup-id padding between matrices (scatters the members over XCDs; tests)
 //   BASD_TRIDIAG_LAG      member that sleeps every step (tests the hand-off under uneven progress)
 //   BASD_TRIDIAG_THREADS  threads per member
-//   BASD_TRIDIAG_TAIL     0: whole factorisation in the shared stage (the round-1 path; tests compare the two)
+//   BASD_TRIDIAG_TAIL     0: whole factorisation in the shared stage (the round-1 path); 2: the four-barrier tail kernel
+//                         (tests compare all three)
 struct TridiagTuning {
     int members = 0, pad = -1, lag = -1, threads = 0, tail = 1;
     TridiagTuning() {
@@ -1172,10 +1524,10 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
     if (tail) {
         MpRankOut in_tail = rk;
         if (!fused_rank) in_tail.rank_out = nullptr;
-        if (g_tuning.tail == 2)      // experiment: 8 waves x 32 rows (cheaper barriers, two waves per SIMD)
-            tridiag_tail_kernel<8, 32, 4><<<batch, 512, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
-        else
+        if (g_tuning.tail == 2)      // the four-barrier form (16 waves): kept for the tests that compare the two
             tridiag_tail_kernel<16, 16, 4><<<batch, 1024, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
+        else
+            tridiag_tail2_kernel<<<batch, 512, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
     }
     if (rk.rank_out && !fused_rank)
         tridiag_mp_rank_kernel<<<rk.count, 1024, 0, stream>>>(d, e, n, rk.factor, rk.cap, rk.rank_out, nullptr, rk.host_mirror ? err : nullptr, rk.host_mirror);
