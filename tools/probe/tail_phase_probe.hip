@@ -1,6 +1,7 @@
 // Where a step of the register-resident tail stage goes: s_memtime stamps of wave 0 and the last wave at the phase
-// boundaries of every step (BASD_TAIL_DBG build of tridiag.hip), n = 256, one matrix.
-#define BASD_TAIL_DBG 1
+// boundaries of every step (compile with -DBASD_TAIL_DBG), and a bit-level fingerprint of the factorisation that must
+// not depend on -DBASD_TAIL_JITTER (waves asleep at the phase boundaries; a -DBASD_TAIL_DBG build is for TIMING only:
+// its scalar-memory stamps disturb the hand-counted LDS waits and the factorisation it computes is garbage).  One matrix.
 #include "../../vit-inductive-bias-distillation_amd/csrc/tridiag.hip"
 #include <stdio.h>
 #include <vector>
@@ -24,19 +25,34 @@ int main(int argc, char** argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("rc %d  %.3f ms\n", rc, ms);
     }
+#ifdef BASD_TAIL_DBG
     std::vector<long long> t(8 * 2 * 1024);
     hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(basd::g_tail_dbg), sizeof(long long) * 8 * 2 * 1024);
+    const int OFF = 0;
     const char* names[] = {"pass", "A-wait", "sum", "scalar", "reflector", "B-wait"};
     for (int jl : {2, 64, 128, 200, 250}) {
         if (jl >= n - 2) continue;
         for (int w = 0; w < 2; ++w) {
             printf("step %3d wave %s:", jl, w ? "last" : "0   ");
-            for (int sl = 0; sl < 6; ++sl) printf(" %s %lld", names[sl], t[(jl * 8 + sl + 1) * 2 + w] - t[(jl * 8 + sl) * 2 + w]);
-            printf(" | next-step start after %lld\n", t[((jl + 1) * 8) * 2 + w] - t[(jl * 8) * 2 + w]);
+            for (int sl = 0; sl < 6; ++sl) printf(" %s %lld", names[sl], t[OFF + (jl * 8 + sl + 1) * 2 + w] - t[OFF + (jl * 8 + sl) * 2 + w]);
+            printf(" | next-step start after %lld\n", t[OFF + ((jl + 1) * 8) * 2 + w] - t[OFF + (jl * 8) * 2 + w]);
         }
     }
+#endif
     std::vector<float> hd(n); hipMemcpy(hd.data(), d, 4 * n, hipMemcpyDeviceToHost);
     double tr = 0, tr0 = 0; for (int i = 0; i < n; ++i) { tr += hd[i]; tr0 += h[(size_t)i * n + i]; }
     printf("trace %.6f vs %.6f\n", tr, tr0);
+    // bit-level fingerprint of (d, e, tau): builds with and without -DBASD_TAIL_JITTER / -DBASD_TAIL_DBG must agree
+    std::vector<unsigned> bits(3 * n);
+    hipMemcpy(bits.data(), d, 4 * n, hipMemcpyDeviceToHost);
+    hipMemcpy(bits.data() + n, e, 4 * n, hipMemcpyDeviceToHost);
+    hipMemcpy(bits.data() + 2 * n, tau, 4 * n, hipMemcpyDeviceToHost);
+    unsigned long long fp = 1469598103934665603ull;
+    for (unsigned b : bits) { fp ^= b; fp *= 1099511628211ull; }
+    std::vector<unsigned> vb((size_t)n * n);
+    hipMemcpy(vb.data(), vh, sizeof(float) * n * n, hipMemcpyDeviceToHost);
+    unsigned long long hv = 1469598103934665603ull;
+    for (unsigned b : vb) { hv ^= b; hv *= 1099511628211ull; }
+    printf("n %d fingerprint d/e/tau %016llx reflectors %016llx\n", n, fp, hv);
     return 0;
 }

@@ -554,11 +554,12 @@ __global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restr
 // the first form issues 8 packed FMAs, 10 v_mov that splat (u_r, v_r, w_r) into register pairs, and a uniform branch.
 // Here
 //   * rows are consumed in pairs (r_a = wave + 16 P, r_b = r_a + 8); per wave and pair LDS holds (v_a, w_a, v_b, w_b)
-//     and (u_a, u_b), fetched two pairs ahead with one b128 + one b64 read, and a wave-uniform operand of a packed FMA is
+//     and (u_a, u_b), fetched one pair ahead with one b128 + one b64 read, and a wave-uniform operand of a packed FMA is
 //     taken from either half of a register pair with op_sel / op_sel_hi: a pair of rows is 12 v_pk_fma_f32 and nothing
 //     else -- no splat by the VALU, no splat by LDS (that form was bound by the LDS return path);
-//   * the pass is entered at its first live pair through a jump table (rows below r0 are finished: the live pairs are a
-//     suffix) and the pivot row is copied out by a second one: two indirect jumps instead of ~70 uniform branches;
+//   * the pass starts at its first live pair (rows below r0 are finished: the live pairs are a suffix): one straight-line
+//     instance per entry pair behind a jump table, and the pivot row is copied out behind a second one: two indirect
+//     jumps instead of ~70 uniform branches;
 //   * lane l of a wave owns the columns c_k = (l & 7) + 32 (l >> 3) + 8 k, k < 4:
 //     exactly the rows of pairs 2 (l >> 3), 2 (l >> 3) + 1 of wave l & 7, so the column form of u, v, w IS the row
 //     operand table -- wave 0 publishes a step with three ds_write_b128 per lane;
@@ -571,10 +572,18 @@ __global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restr
 // Same arithmetic as the first form (same update order, same reflector formulas).
 // ---------------------------------------------------------------------------
 #ifdef BASD_TAIL_DBG
+// s_memtime stamps at the phase boundaries (tools/probe/tail_phase_probe.hip)
 __device__ long long g_tail_dbg[8 * 2 * 1024];
 #define TAIL_STAMP(slot) do { if (z == 0 && lane == 0 && (wave == 0 || wave == WAVES - 1)) g_tail_dbg[(jl * 8 + (slot)) * 2 + (wave != 0)] = clock64(); } while (0)
 #else
 #define TAIL_STAMP(slot) do { } while (0)
+#endif
+// test builds (EXTRA=-DBASD_TAIL_JITTER): waves fall asleep at the phase boundaries in a wave- and step-dependent pattern;
+// results must not change by a bit (tools/probe/tail_phase_probe.hip checks against the four-barrier kernel)
+#ifdef BASD_TAIL_JITTER
+#define TAIL_JITTER(slot) do { if (((wave * 7 + jl * 3 + (slot)) % 5) == 0) __builtin_amdgcn_s_sleep(60); } while (0)
+#else
+#define TAIL_JITTER(slot) do { } while (0)
 #endif
 typedef float tri_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lane_bcast(float x, int l) {
@@ -611,20 +620,10 @@ __device__ __forceinline__ void lds_read8_b128(unsigned addr, tri_f32x4 (&x)[8])
         : "memory");
 }
 __device__ __forceinline__ void pkfma_lo(tri_f2& a, tri_f2 p, tri_f2 b) {      // a += p.x * b
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a) : "v"(p), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a) : "v"(p), "v"(b));
 }
 __device__ __forceinline__ void pkfma_hi(tri_f2& a, tri_f2 p, tri_f2 b) {      // a += p.y * b
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(p), "v"(b));
-}
-template <int P>
-__device__ __forceinline__ void lds_pair_issue(unsigned bvw, unsigned bu2, tri_f32x4& vw, tri_f2& u2) {
-    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%5"
-                 : "=&v"(vw), "=&v"(u2) : "v"(bvw), "v"(bu2), "n"(16 * P), "n"(8 * P) : "memory");
-}
-// the registers only hold the pair's operands behind this wait; NEWER = LDS reads issued after them
-template <int NEWER>
-__device__ __forceinline__ void lds_pair_wait(tri_f32x4& vw, tri_f2& u2) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vw), "+v"(u2) : "n"(NEWER) : "memory");
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(a) : "v"(p), "v"(b));
 }
 // rows r_a, r_b of one pair:  a' = a - w_r v_c - v_r w_c ;  acc_c += a' u_r   (nvc = -v_c, nwc = -w_c)
 __device__ __forceinline__ void tail_pair_update(tri_f2 (&ra)[2], tri_f2 (&rb)[2], tri_f32x4 vw, tri_f2 u2,
@@ -636,17 +635,24 @@ __device__ __forceinline__ void tail_pair_update(tri_f2 (&ra)[2], tri_f2 (&rb)[2
         pkfma_hi(rb[q], pb, nvc[q]);
         pkfma_lo(ra[q], pa, nwc[q]);
         pkfma_lo(rb[q], pb, nwc[q]);
-        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[q]) : "v"(ra[q]), "v"(u2));
-        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc[q]) : "v"(rb[q]), "v"(u2));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[q]) : "v"(ra[q]), "v"(u2));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc[q]) : "v"(rb[q]), "v"(u2));
     }
 }
 
-#define TAIL_PAIR(P)                                                                                              \
-    case P: {                                                                                                     \
-        if ((P) + DIST < NP) lds_pair_issue<(P) + DIST>(bvw, bu2, vw[((P) + DIST) % NBUF], u2[((P) + DIST) % NBUF]); \
-        lds_pair_wait<2 * ((P) + DIST < NP ? DIST : NP - 1 - (P))>(vw[(P) % NBUF], u2[(P) % NBUF]);               \
-        tail_pair_update(a[2 * (P)], a[2 * (P) + 1], vw[(P) % NBUF], u2[(P) % NBUF], nvc, nwc, acc);              \
-    }                                                                                                             \
+// One pair of the pass.  The operands of pair P were requested while pair P - 1 was computed (plain LDS loads: the
+// compiler places the waits, also across the case labels through which the pass is entered at its first live pair);
+// hand-counted s_waitcnt around asm reads would leave stale registers in front of every control-flow join.
+#define TAIL_PAIR(P)                                                                             \
+    case P: {                                                                                    \
+        const tri_f32x4 cvw = nvw;                                                               \
+        const tri_f2 cu = nu;                                                                    \
+        if ((P) + 1 < NP) {                                                                      \
+            nvw = opvw[(P) + 1 < NP ? (P) + 1 : (P)];                                            \
+            nu = opu[(P) + 1 < NP ? (P) + 1 : (P)];                                              \
+        }                                                                                        \
+        tail_pair_update(a[2 * (P)], a[2 * (P) + 1], cvw, cu, nvc, nwc, acc);                    \
+    }                                                                                            \
     [[fallthrough]];
 #define TAIL_CAP(I)                                                                                               \
     case I:                                                                                                       \
@@ -699,7 +705,6 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
         const int r = idx / j0, c = idx - r * j0;
         Vz[(long)(j0 + r) * n + c] = 0.f;
     }
-    const unsigned bvw = (unsigned)(uintptr_t)&op_vw[wave][0], bu2 = (unsigned)(uintptr_t)&op_u[wave][0];
     // where this lane's columns sit in the operand tables (as rows): wave lane % WAVES, pairs 2 (lane / WAVES) and + 1
     tri_f32x4* const my_vw = &op_vw[lane & (WAVES - 1)][2 * (lane >> LW)];
     tri_f32x4* const my_u = (tri_f32x4*)&op_u[lane & (WAVES - 1)][2 * (lane >> LW)];
@@ -765,6 +770,7 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
         const int r0 = jl + 1;
         // ---- pass over the registers
         TAIL_STAMP(0);
+        TAIL_JITTER(0);
         tri_f2 nvc[2], nwc[2], acc[2];
         {
             const tri_f32x4 o0 = my_vw[0], o1 = my_vw[1];
@@ -775,19 +781,10 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
         {
             // first pair with a live row: rows wave + 2 WAVES P and + WAVES against r0
             const int p0 = r0 > wave + WAVES ? (r0 - wave - WAVES + 2 * WAVES - 1) >> (LW + 1) : 0;
-            // operands in flight two pairs ahead: with two waves per SIMD one pair of FMAs does not cover an LDS round trip
-            constexpr int DIST = 2, NBUF = DIST + 1;
-            tri_f32x4 vw[NBUF];
-            tri_f2 u2[NBUF];
-            if (p0 < NP) {
-                const int p1 = p0 + 1 < NP ? p0 + 1 : p0;
-                const unsigned a0 = bvw + 16 * p0, b0 = bu2 + 8 * p0, a1 = bvw + 16 * p1, b1 = bu2 + 8 * p1;
-                switch (p0 % 3) {
-                    case 0: lds_pair_issue<0>(a0, b0, vw[0], u2[0]); lds_pair_issue<0>(a1, b1, vw[1], u2[1]); break;
-                    case 1: lds_pair_issue<0>(a0, b0, vw[1], u2[1]); lds_pair_issue<0>(a1, b1, vw[2], u2[2]); break;
-                    default: lds_pair_issue<0>(a0, b0, vw[2], u2[2]); lds_pair_issue<0>(a1, b1, vw[0], u2[0]); break;
-                }
-            }
+            const tri_f32x4* const opvw = &op_vw[wave][0];
+            const tri_f2* const opu = &op_u[wave][0];
+            tri_f32x4 nvw = opvw[p0 < NP ? p0 : 0];
+            tri_f2 nu = opu[p0 < NP ? p0 : 0];
             switch (p0) {
                 TAIL_PAIR(0)
                 TAIL_PAIR(1)
@@ -847,8 +844,10 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
         }
         part4[wave][lane] = tri_f32x4{acc[0].x, acc[0].y, acc[1].x, acc[1].y};
         TAIL_STAMP(1);
+        TAIL_JITTER(1);
         lds_barrier();                                                                     // A
         TAIL_STAMP(2);
+        TAIL_JITTER(2);
         if (wave == 0) {
             // ---- the scalar part of the step: one wave, wave-level sums only
             tri_f32x4 x8[8];
@@ -859,6 +858,7 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
             pc[0] = tau * s4.x; pc[1] = tau * s4.y; pc[2] = tau * s4.z; pc[3] = tau * s4.w;
             capc[0] = c4.x; capc[1] = c4.y; capc[2] = c4.z; capc[3] = c4.w;
             TAIL_STAMP(3);
+            TAIL_JITTER(3);
             float dot = 0.f;
 #pragma unroll
             for (int k = 0; k < CPL; ++k) dot = fmaf(pc[k], uc[k], dot);
@@ -871,11 +871,14 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
                 cn[k] = on ? capc[k] - fmaf(uc[k], w0, wn[k]) : 0.f;
             }
             TAIL_STAMP(4);
+            TAIL_JITTER(4);
             next_reflector(jl + 1, jl + 1 >= m - 1);
             TAIL_STAMP(5);
+            TAIL_JITTER(5);
         }
         lds_barrier();                                                                     // B
         TAIL_STAMP(6);
+        TAIL_JITTER(6);
         if (wave == WAVES - 1) store_reflector(jl + 1);
     }
     lds_barrier();
