@@ -26,9 +26,9 @@ int main(int argc, char** argv) {
         printf("rc %d  %.3f ms\n", rc, ms);
     }
 #ifdef BASD_TAIL_DBG
-    std::vector<long long> t(8 * 2 * 1024);
-    hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(basd::g_tail_dbg), sizeof(long long) * 8 * 2 * 1024);
-    const int OFF = 0;
+    std::vector<long long> t(2 * 8 * 2 * 1024);
+    hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(basd::g_tail_dbg), sizeof(long long) * 2 * 8 * 2 * 1024);
+    const int OFF = 8 * 2 * 1024;      // basd_tridiag delivers no ranks: second stamp set
     const char* names[] = {"pass", "A-wait", "sum", "scalar", "reflector", "B-wait"};
     for (int jl : {2, 64, 128, 200, 250}) {
         if (jl >= n - 2) continue;

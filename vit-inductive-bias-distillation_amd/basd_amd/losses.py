@@ -541,7 +541,9 @@ class GrassmannianLayerSelector(nn.Module):
         def student_chain(gate=None):
             """centred Grams -> eigen-solve of the E student layers; ``gate``: event the chain waits for first"""
             with torch.cuda.stream(student_stream if student_stream is not None else cur):
-                if gate is not None:
+                if isinstance(gate, torch.cuda.Event):
+                    torch.cuda.current_stream().wait_event(gate)
+                elif gate is not None:
                     ops.stream_wait_event(torch.cuda.current_stream(), gate)
                 # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
                 # proj_s^T instead of the student tokens by proj_s (layer_selector.py:88 folded into :99)
@@ -585,8 +587,14 @@ class GrassmannianLayerSelector(nn.Module):
             # once, and only then are the centred spectra (needed by the eigenvector stage alone) queued.
             # ranks straight out of the factorisation's last kernel                          (:16-19, :74)
             pin = self._pinned_ints("teacher", L + 8)
-            gate = None
-            if gated:
+            # Where the gate sits.  Student layers that feed this step's loss (several teacher layers): behind the
+            # teacher's multi-workgroup stage, as early as the spinning members allow.  One teacher layer (the student
+            # chain feeds nothing this step): behind the WHOLE teacher factorisation -- released at the hand-over, its
+            # Gram launch floods the chip in the very moment the teacher's one-workgroup tail kernel looks for a CU
+            # with 8 free wave slots and 2 x 192 VGPRs per SIMD (100 MHz stamps inside a step, tools/
+            # tail_stamps_in_step.py: 474 us between the end of the shared stage and the tail kernel's first instruction).
+            gate, gate_after_ranks = None, gated and defer_student
+            if gated and not gate_after_ranks:
                 if getattr(self, "_gate_event", None) is None:
                     self._gate_event = ops.new_event()
                 gate = self._gate_event
@@ -600,6 +608,8 @@ class GrassmannianLayerSelector(nn.Module):
             if chain_t0 is not None:
                 ops.CHAIN_EVENTS.append((chain_t0, ready))
             ops.tridiag_spectrum(ts, first=o_c, count=L)
+            if gate_after_ranks:
+                gate = self._gate_event = ready
             if gated and defer_student:
                 st["queue_student"] = lambda: student_chain(gate)
             elif gated:
@@ -1025,7 +1035,9 @@ class BASDLoss(nn.Module):
                     tail.wait_event(ev)
                 # queued one step later (see below): then also behind that step's multi-workgroup tridiagonalisation
                 # stage, like its student chain -- the members of that stage must not queue for CUs behind these kernels
-                if gate_tail and getattr(sel, "_gate_event", None) is not None:
+                if gate_tail and isinstance(getattr(sel, "_gate_event", None), torch.cuda.Event):
+                    tail.wait_event(sel._gate_event)
+                elif gate_tail and getattr(sel, "_gate_event", None) is not None:
                     ops.stream_wait_event(tail, sel._gate_event)
                 ops.trace("tail_waits")
                 # only what the tail reads needs marking (every marked block costs an event when it is freed)

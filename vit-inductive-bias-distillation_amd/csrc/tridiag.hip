@@ -86,6 +86,11 @@ __device__ __forceinline__ void load8_rows(float4 (&a)[8], const float* p0, cons
     a[6] = make_float4(x6.x, x6.y, x6.z, x6.w); a[7] = make_float4(x7.x, x7.y, x7.z, x7.w);
 }
 
+#ifdef BASD_TAIL_DBG
+// diagnostic builds: s_memtime / 100 MHz stamps of the last factorisations (tools/tail_stamps_in_step.py); two sets:
+// launches that also deliver the ranks (the chain the host waits for) and the others
+__device__ long long g_tail_dbg[2 * 8 * 2 * 1024];
+#endif
 constexpr int TRI_RB = 8;      // rows per group: RB independent load streams keep L2 latency covered
 constexpr int TRI_BLK = 32;    // rows per ownership block (4 groups)
 
@@ -111,6 +116,10 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
     // kernels of other streams (Gram MFMA loops, the Procrustes Jacobi).  Top wave priority makes the issue
     // arbiter serve these waves first; the background kernels lose next to nothing.
     __builtin_amdgcn_s_setprio(3);
+#ifdef BASD_TAIL_DBG
+    // 100 MHz clock at the begin / end of the shared stage (workgroup 0; set 0: the two-matrix teacher launch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_tail_dbg[(batch == 2 ? 0 : 8 * 2 * 1024) + 8 * 2 * 1024 - 8] = wall_clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* v = sm;             // previous reflector
     float* w = sm + n;         // its w = p + gamma v
@@ -317,6 +326,9 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
         if (j + 1 < n - 1 && j + 1 < j_stop) form_reflector(j + 1, xn2);
     }
     __syncthreads();
+#ifdef BASD_TAIL_DBG
+    if (p == last_owner && z == 0 && threadIdx.x == 0) g_tail_dbg[(batch == 2 ? 0 : 8 * 2 * 1024) + 8 * 2 * 1024 - 7] = wall_clock64();
+#endif
     if (budget <= 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (j_stop < n - 1) {
         // hand-over: the owner of row j_stop was in step to the end, its (v, w) are those of step j_stop - 1
@@ -573,10 +585,12 @@ __global__ void __launch_bounds__(64 * WAVES) tridiag_tail_kernel(float* __restr
 // ---------------------------------------------------------------------------
 #ifdef BASD_TAIL_DBG
 // s_memtime stamps at the phase boundaries (tools/probe/tail_phase_probe.hip)
-__device__ long long g_tail_dbg[8 * 2 * 1024];
-#define TAIL_STAMP(slot) do { if (z == 0 && lane == 0 && (wave == 0 || wave == WAVES - 1)) g_tail_dbg[(jl * 8 + (slot)) * 2 + (wave != 0)] = clock64(); } while (0)
+#define TAIL_STAMP(slot) do { if (z == 0 && lane == 0 && (wave == 0 || wave == WAVES - 1)) g_tail_dbg[(rk.rank_out ? 0 : 8 * 2 * 1024) + (jl * 8 + (slot)) * 2 + (wave != 0)] = clock64(); } while (0)
+// shader clock against the constant 100 MHz clock over the whole step loop (last four words of the set)
+#define TAIL_CLOCKS(which) do { if (z == 0 && tid == 0) { long long* q_ = g_tail_dbg + (rk.rank_out ? 0 : 8 * 2 * 1024) + 8 * 2 * 1024 - 4 + 2 * (which); q_[0] = clock64(); q_[1] = wall_clock64(); } } while (0)
 #else
 #define TAIL_STAMP(slot) do { } while (0)
+#define TAIL_CLOCKS(which) do { } while (0)
 #endif
 // test builds (EXTRA=-DBASD_TAIL_JITTER): waves fall asleep at the phase boundaries in a wave- and step-dependent pattern;
 // results must not change by a bit (tools/probe/tail_phase_probe.hip checks against the four-barrier kernel)
@@ -666,6 +680,9 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
     // 8 waves: two per SIMD (a 16-wave variant of this form was no faster and needs more than its 128 VGPRs)
     constexpr int WAVES = 8, LW = 3, CPL = 4, MMAX = 64 * CPL, RPW = MMAX / WAVES, NP = RPW / 2;   // row r = wave + WAVES i
     __builtin_amdgcn_s_setprio(3);
+#ifdef BASD_TAIL_DBG
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_tail_dbg[(rk.rank_out ? 0 : 8 * 2 * 1024) + 8 * 2 * 1024 - 6] = wall_clock64();
+#endif
     __shared__ tri_f32x4 op_vw[WAVES][NP];        // (v_a, w_a, v_b, w_b) of the wave's pair P: rows wave + 2 WAVES P, + WAVES
     __shared__ __attribute__((aligned(16))) tri_f2 op_u[WAVES][NP];   // (u_a, u_b)
     __shared__ tri_f32x4 part4[WAVES][64];        // per-wave column partials of the lane's four columns
@@ -758,6 +775,7 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
         if (cbase + 2 * WAVES < m) vrow[cbase + 2 * WAVES] = u4.z;
         if (cbase + 3 * WAVES < m) vrow[cbase + 3 * WAVES] = u4.w;
     };
+    TAIL_CLOCKS(0);
     if (wave == 0) {
 #pragma unroll
         for (int k = 0; k < CPL; ++k) cn[k] = a[0][k >> 1][k & 1];
@@ -881,6 +899,7 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
         TAIL_JITTER(6);
         if (wave == WAVES - 1) store_reflector(jl + 1);
     }
+    TAIL_CLOCKS(1);
     lds_barrier();
     for (int c = tid; c < m; c += 64 * WAVES) {
         dz[j0 + c] = dloc[c];
@@ -897,6 +916,9 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
         __syncthreads();
         mp_rank_block(dl, el, n, z, rk, nullptr);
     }
+#ifdef BASD_TAIL_DBG
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_tail_dbg[(rk.rank_out ? 0 : 8 * 2 * 1024) + 8 * 2 * 1024 - 5] = wall_clock64();
+#endif
 }
 #undef TAIL_PAIR
 #undef TAIL_CAP
@@ -1490,11 +1512,34 @@ struct TridiagTuning {
 };
 static TridiagTuning g_tuning;
 
+// Workgroups of one shared-stage launch that may spin on each other: all of them must be resident together, beside
+// whatever the other streams keep on the chip.  Half of what the device can hold of this kernel (occupancy query for
+// the actual kernel, 1024 threads, its LDS; once per process and n), never more than 128 -- on a 256-CU MI355X that
+// is the old rule (two concurrent launches fit even at one workgroup per CU); a smaller or partitioned device
+// gets a smaller budget, down to one member per matrix (no exchange at all).
+static int tridiag_resident_budget(int n) {
+    static std::atomic<int> cached_n{0}, cached_budget{0};
+    if (cached_n.load(std::memory_order_acquire) == n) return cached_budget.load(std::memory_order_relaxed);
+    int dev = 0, cus = 0, per_cu = 0, budget = 128;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)tridiag_kernel<true, true>, 1024,
+                                                     sizeof(float) * 9 * (size_t)n) == hipSuccess &&
+        cus > 0 && per_cu > 0) {
+        budget = per_cu * cus / 2;
+        if (budget > 128) budget = 128;
+    }
+    cached_budget.store(budget, std::memory_order_relaxed);
+    cached_n.store(n, std::memory_order_release);
+    return budget;
+}
+
 static int tridiag_members(int n, int batch) {
     const int nblk = nblk_of(n);
     int p = g_tuning.members > 0 ? g_tuning.members : nblk;
     if (p > 16) p = 16;
-    while (p > 1 && p * batch > 128) --p;
+    const int budget = tridiag_resident_budget(n);
+    while (p > 1 && p * batch > budget) --p;
     if (p > nblk) p = nblk;
     return p < 1 ? 1 : p;
 }
@@ -1642,6 +1687,13 @@ int basd_tridiag_mp_rank(const float* d, const float* e, int n, int batch, doubl
     tridiag_mp_rank_kernel<<<batch, 1024, 0, stream>>>(d, e, n, factor, cap, rank_out, thr_out, status, host_mirror);
     BASD_RETURN_LAST();
 }
+
+#ifdef BASD_TAIL_DBG
+// stamped builds only (tools/tail_stamps_in_step.py): the s_memtime stamps of the last tail-stage launches
+int basd_debug_tail_stamps(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(basd::g_tail_dbg), sizeof(long long) * 2 * 8 * 2 * 1024);
+}
+#endif
 
 // Top-k eigenvectors of the ORIGINAL matrices (rows of vecs: (batch, k_stride, n), first k rows written).
 // z: batch * k * n floats of scratch (eigenvectors of the tridiagonals).
