@@ -140,9 +140,7 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
 int basd_tridiag_ranked(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
                         void* work, int rank_count, double factor, int cap, int* rank_out, int* host_mirror,
                         void* mid_event /* nullable hipEvent_t: recorded behind the multi-workgroup stage */,
-                        unsigned* started_word /* nullable device word: receives started_value with the FIRST instruction of
-                                                  the last (one workgroup per matrix) kernel -- see basd_stream_wait_value32 */,
-                        unsigned started_value, hipStream_t stream);
+                        hipStream_t stream);
 
 /* Test / tuning hook for basd_tridiag (the only process-wide setting of the library; its defaults come from the
  * BASD_TRIDIAG_{MEMBERS,PAD,LAG,THREADS,TAIL} environment variables, read ONCE when the library is loaded -- no
@@ -330,9 +328,6 @@ int basd_cross_entropy(const void* logits, int dtype, long ld, int B, int C, con
 int basd_event_create(void** out);
 int basd_event_destroy(void* event);
 int basd_stream_wait_event(hipStream_t stream, void* event);
-/* The stream goes on once *word >= value (hipStreamWaitValue32): ordering behind the START of a kernel that writes the
- * word with its first instruction, which no event can express. */
-int basd_stream_wait_value32(hipStream_t stream, unsigned* word, unsigned value);
 
 /* ---- multi-layer teachers only: gradients through the mixing weights and the principal angles ------ */
 

@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbasd_hip.so")
 
-vp, i32, i64, f32, f64, u32 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
 # name -> argtypes (return type is always int)
 SIGNATURES = {
@@ -33,8 +33,7 @@ SIGNATURES = {
     "basd_tridiag_workspace_bytes": [i32, i32],
     "basd_tridiag_tuning": [i32, i32, i32, i32, i32, i32],
     "basd_tridiag": [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp],
-    "basd_tridiag_ranked": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp, vp, u32, vp],
-    "basd_stream_wait_value32": [vp, vp, u32],
+    "basd_tridiag_ranked": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp, vp],
     "basd_event_create": [vp],
     "basd_event_destroy": [vp],
     "basd_stream_wait_event": [vp, vp],

@@ -541,8 +541,8 @@ class GrassmannianLayerSelector(nn.Module):
         def student_chain(gate=None):
             """centred Grams -> eigen-solve of the E student layers; ``gate``: event the chain waits for first"""
             with torch.cuda.stream(student_stream if student_stream is not None else cur):
-                if isinstance(gate, ops.StartGate):
-                    gate.hold(torch.cuda.current_stream())
+                if isinstance(gate, torch.cuda.Event):
+                    torch.cuda.current_stream().wait_event(gate)
                 elif gate is not None:
                     ops.stream_wait_event(torch.cuda.current_stream(), gate)
                 # proj_s is orthogonal: principal angles are unchanged if the teacher bases are rotated by
@@ -587,20 +587,15 @@ class GrassmannianLayerSelector(nn.Module):
             # once, and only then are the centred spectra (needed by the eigenvector stage alone) queued.
             # ranks straight out of the factorisation's last kernel                          (:16-19, :74)
             pin = self._pinned_ints("teacher", L + 8)
-            # Where the gate sits.  Student layers that feed this step's loss (several teacher layers): an event behind
-            # the teacher's multi-workgroup stage, as early as the spinning members allow.  One teacher layer (the student
-            # chain feeds nothing this step): the START of the teacher's one-workgroup tail kernel.  Released by an event
-            # at the hand-over, the student Gram launch floods the chip in the very moment that kernel looks for a CU
+            # Where the gate sits.  Student layers that feed this step's loss (several teacher layers): behind the
+            # teacher's multi-workgroup stage, as early as the spinning members allow.  One teacher layer (the student
+            # chain feeds nothing this step): behind the WHOLE teacher factorisation -- released at the hand-over, its
+            # Gram launch floods the chip in the very moment the teacher's one-workgroup tail kernel looks for a CU
             # with 8 free wave slots and 2 x 192 VGPRs per SIMD (100 MHz stamps inside a step, tools/
-            # tail_stamps_in_step.py: 474 us between the end of the shared stage and the tail kernel's first
-            # instruction); released by the kernel itself, it starts ~2 us after the tail has its CU.
-            gate = None
-            if gated and defer_student and os.environ.get("BASD_TRIDIAG_TAIL", "1") == "1":   # the kernel with the word
-                if not isinstance(getattr(self, "_gate_event", None), ops.StartGate):
-                    self._gate_event = ops.StartGate(t_stack.device)
-                gate = self._gate_event
-            elif gated:
-                if not isinstance(getattr(self, "_gate_event", None), int):
+            # tail_stamps_in_step.py: 474 us between the end of the shared stage and the tail kernel's first instruction).
+            gate, gate_after_ranks = None, gated and defer_student
+            if gated and not gate_after_ranks:
+                if getattr(self, "_gate_event", None) is None:
                     self._gate_event = ops.new_event()
                 gate = self._gate_event
             ts = ops.tridiagonalise(t_stack, mp_rank=(M, d_s, d_s - 1, L, pin, gate))
@@ -613,6 +608,8 @@ class GrassmannianLayerSelector(nn.Module):
             if chain_t0 is not None:
                 ops.CHAIN_EVENTS.append((chain_t0, ready))
             ops.tridiag_spectrum(ts, first=o_c, count=L)
+            if gate_after_ranks:
+                gate = self._gate_event = ready
             if gated and defer_student:
                 st["queue_student"] = lambda: student_chain(gate)
             elif gated:
@@ -931,12 +928,6 @@ class BASDLoss(nn.Module):
         # (or ``sync_ranks = False``): with one teacher layer the ranks do not feed the loss, the read-back is then
         # completed by the next forward / the first reader of ``subspace_ranks`` and consecutive steps may overlap.
         self.sync_ranks = os.environ.get("BASD_RANK_READBACK", "sync") != "deferred"
-        # One teacher layer (every CNN teacher): the mixing weights are softmax over ONE distance = 1 whatever the
-        # student-side subspaces and principal angles are, so nothing the reference computes from them can be observed
-        # (loss, gradients, ``subspace_ranks`` are unaffected).  Default False: compute them like the reference does.
-        # True skips exactly that work in single-teacher steps (student Grams / eigen-solves, eigenvectors, principal
-        # angles); the teacher's Marchenko-Pastur rank is still computed and raised on.  Opt-in, never used by bench.py.
-        self.observable_only = os.environ.get("BASD_OBSERVABLE_ONLY", "0") == "1"
 
     def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
         key = (str(device), index)
@@ -1000,8 +991,6 @@ class BASDLoss(nn.Module):
             # the student chain waits for the teacher's first tridiagonalisation stage on the GPU anyway: queue it now,
             # behind the Procrustes kernels, instead of in front of them
             queue_student = spectra.pop("queue_student", None)
-            if self.observable_only:
-                queue_student = None        # see the attribute: nothing of the student side is observable here
             if queue_student is not None:
                 with torch.cuda.stream(side):
                     queue_student()
@@ -1046,8 +1035,8 @@ class BASDLoss(nn.Module):
                     tail.wait_event(ev)
                 # queued one step later (see below): then also behind that step's multi-workgroup tridiagonalisation
                 # stage, like its student chain -- the members of that stage must not queue for CUs behind these kernels
-                if gate_tail and isinstance(getattr(sel, "_gate_event", None), ops.StartGate):
-                    sel._gate_event.hold(tail)
+                if gate_tail and isinstance(getattr(sel, "_gate_event", None), torch.cuda.Event):
+                    tail.wait_event(sel._gate_event)
                 elif gate_tail and getattr(sel, "_gate_event", None) is not None:
                     ops.stream_wait_event(tail, sel._gate_event)
                 ops.trace("tail_waits")
@@ -1081,7 +1070,7 @@ class BASDLoss(nn.Module):
                 # launches that would otherwise sit between the read-back and the caller's backward).
                 sel.finish_pending()
                 ranks = read_ranks()
-                sel._pending_tail = None if self.observable_only else (lambda: queue_tail(ranks, gate_tail=True))
+                sel._pending_tail = lambda: queue_tail(ranks, gate_tail=True)
             else:
                 # deferred: the PREVIOUS step's ranks are read now (its rank kernel finished long ago; if not,
                 # this wait is the back-pressure that keeps the host at most one step ahead), this step's by the

@@ -262,11 +262,10 @@ class TridiagState:
 def tridiagonalise(G: torch.Tensor, mp_rank: tuple | None = None) -> TridiagState:
     """G (batch, n, n) symmetric, DESTROYED.  Queues the Householder tridiagonalisation; ``vals`` is allocated but
     not filled (``tridiag_spectrum``).  No host sync.
-    ``mp_rank`` = (M, D, cap, count, host_mirror | None[, gate]): also the Marchenko-Pastur ranks of the first ``count``
+    ``mp_rank`` = (M, D, cap, count, host_mirror | None[, mid_event handle | None]): also the Marchenko-Pastur ranks of the first ``count``
     matrices (``ts.ranks``, int32 on device), from the kernel that finishes the factorisation; ``host_mirror``: pinned
     int32 host tensor of count + 8 elements filled with the ranks and the status words (read it after an event
-    recorded behind this call).  ``gate``: a raw event handle recorded behind the multi-workgroup stage, or a
-    ``StartGate`` whose word the last kernel writes with its first instruction."""
+    recorded behind this call)."""
     _require_cuda(G)
     assert G.dtype == torch.float32 and G.is_contiguous() and G.dim() == 3 and G.shape[1] == G.shape[2]
     batch, n, _ = G.shape
@@ -280,39 +279,15 @@ def tridiagonalise(G: torch.Tensor, mp_rank: tuple | None = None) -> TridiagStat
         _lib.call("basd_tridiag", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
                   vh.data_ptr(), work.data_ptr(), _stream())
     else:
-        M, D, cap, count, mirror, gate = (tuple(mp_rank) + (None,))[:6]
-        mid_event, started_word, started_value = gate, None, 0
-        if isinstance(gate, StartGate):
-            mid_event, started_word, started_value = None, gate.word.data_ptr(), gate.arm()
+        M, D, cap, count, mirror, mid_event = (tuple(mp_rank) + (None,))[:6]
         factor = (1 + (D / M) ** 0.5) ** 2          # float64 on the host, as reference layer_selector.py:11,18
         ranks = torch.empty((count,), device=G.device, dtype=torch.int32)
         if mirror is not None:
             assert mirror.is_pinned() and mirror.dtype == torch.int32 and mirror.numel() == count + 8
         _lib.call("basd_tridiag_ranked", G.data_ptr(), n * n, n, batch, d.data_ptr(), e.data_ptr(), tau.data_ptr(),
                   vh.data_ptr(), work.data_ptr(), count, factor, cap, ranks.data_ptr(), _ptr(mirror), mid_event,
-                  started_word, started_value, _stream())
+                  _stream())
     return TridiagState(d, e, tau, vh, vals, work[-32:].view(torch.int32), ranks)
-
-
-class StartGate:
-    """Orders streams behind the START of a kernel (an event can only say that the kernel in front has finished): a
-    device word the kernel writes with its first instruction, a counter that grows by one per use, and
-    ``hipStreamWaitValue32(word >= counter)`` on the streams that were held back."""
-
-    def __init__(self, device: torch.device) -> None:
-        self.word = torch.zeros((1,), device=device, dtype=torch.int32)
-        self.value = 0
-
-    def arm(self) -> int:
-        self.value = (self.value + 1) & 0x7FFFFFFF
-        if self.value == 0:                       # wrapped: start over (once per 2^31 steps)
-            self.word.zero_()
-            self.value = 1
-        return self.value
-
-    def hold(self, stream: "torch.cuda.Stream") -> None:
-        """``stream`` goes on once the kernel armed last has started."""
-        _lib.call("basd_stream_wait_value32", stream.cuda_stream, self.word.data_ptr(), self.value)
 
 
 def new_event() -> int:

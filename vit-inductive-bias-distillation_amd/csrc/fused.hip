@@ -86,12 +86,6 @@ int basd_event_destroy(void* ev) {
     hipError_t e = hipEventDestroy((hipEvent_t)ev);
     return e == hipSuccess ? BASD_OK : (int)e;
 }
-// The stream goes on once *word >= value (a device word written by a kernel, e.g. basd_tridiag_ranked's started_word).
-int basd_stream_wait_value32(hipStream_t stream, unsigned* word, unsigned value) {
-    BASD_CHECK_ARG(word);
-    hipError_t e = hipStreamWaitValue32(stream, word, value, hipStreamWaitValueGte, 0xFFFFFFFFu);
-    return e == hipSuccess ? BASD_OK : (int)e;
-}
 int basd_stream_wait_event(hipStream_t stream, void* ev) {
     BASD_CHECK_ARG(ev);
     hipError_t e = hipStreamWaitEvent(stream, (hipEvent_t)ev, 0);

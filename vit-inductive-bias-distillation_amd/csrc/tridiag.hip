@@ -375,8 +375,6 @@ struct MpRankOut {
     const int* status;    // nullable: 8 status words of the factorisation, copied behind the ranks
     double factor;
     int cap, count;
-    unsigned* started;    // nullable: device word that receives started_value with the tail kernel's FIRST instruction
-    unsigned started_value;
 };
 __device__ __forceinline__ void mp_rank_block(const float* dz, const float* ez, int n, int z, const MpRankOut& o,
                                               float* thr_out);
@@ -682,11 +680,6 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
     // 8 waves: two per SIMD (a 16-wave variant of this form was no faster and needs more than its 128 VGPRs)
     constexpr int WAVES = 8, LW = 3, CPL = 4, MMAX = 64 * CPL, RPW = MMAX / WAVES, NP = RPW / 2;   // row r = wave + WAVES i
     __builtin_amdgcn_s_setprio(3);
-    // "I have a CU": streams that were held back so that this one-workgroup kernel finds room (hipStreamWaitValue32 on
-    // the word) may go on.  An event could only say "the kernel in front of me has finished" -- released then, a
-    // chip-filling launch of another stream takes the CUs first and this kernel waits for a place (measured: 474 us).
-    if (rk.started && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(rk.started, rk.started_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef BASD_TAIL_DBG
     if (blockIdx.x == 0 && threadIdx.x == 0) g_tail_dbg[(rk.rank_out ? 0 : 8 * 2 * 1024) + 8 * 2 * 1024 - 6] = wall_clock64();
 #endif
@@ -1378,7 +1371,7 @@ __global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __re
                                                                int* __restrict__ host_mirror) {
     __builtin_amdgcn_s_setprio(3);     // the host is waiting for this kernel: see tridiag_kernel
     const int z = blockIdx.x;
-    const MpRankOut o{rank_out, host_mirror, status, factor, cap, (int)gridDim.x, nullptr, 0u};
+    const MpRankOut o{rank_out, host_mirror, status, factor, cap, (int)gridDim.x};
     mp_rank_block(d + (long)z * n, e + (long)z * n, n, z, o, thr_out);
 }
 
@@ -1627,7 +1620,7 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
 
 int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
                  void* work, hipStream_t stream) {
-    return tridiag_impl(a, a_batch_stride, n, batch, d, e, tau, vh, work, MpRankOut{nullptr, nullptr, nullptr, 0., 0, 0, nullptr, 0u}, stream);
+    return tridiag_impl(a, a_batch_stride, n, batch, d, e, tau, vh, work, MpRankOut{nullptr, nullptr, nullptr, 0., 0, 0}, stream);
 }
 
 // basd_tridiag + the Marchenko-Pastur ranks (basd_tridiag_mp_rank) of the FIRST rank_count matrices of the batch, computed
@@ -1635,12 +1628,12 @@ int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, floa
 // (nullable): pinned host memory of rank_count + 8 ints -- the ranks, then the factorisation's 8 status words.
 int basd_tridiag_ranked(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
                         void* work, int rank_count, double factor, int cap, int* rank_out, int* host_mirror,
-                        void* mid_event, unsigned* started_word, unsigned started_value, hipStream_t stream) {
+                        void* mid_event, hipStream_t stream) {
     BASD_CHECK_ARG(rank_out && rank_count > 0 && rank_count <= batch);
     if (n > 8192) return BASD_EUNSUPPORTED;
     return tridiag_impl(a, a_batch_stride, n, batch, d, e, tau, vh, work,
-                        MpRankOut{rank_out, host_mirror, nullptr, factor, cap, rank_count, started_word, started_value},
-                        stream, (hipEvent_t)mid_event);
+                        MpRankOut{rank_out, host_mirror, nullptr, factor, cap, rank_count}, stream,
+                        (hipEvent_t)mid_event);
 }
 
 // All eigenvalues (descending) of the tridiagonals by Sturm bisection.
