@@ -18,6 +18,7 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import socket
@@ -231,6 +232,12 @@ def main() -> None:
 
     for _ in range(args.warmup):
         loss = step()
+    # Python's cyclic collector: a generation-2 pass over the ~10^6 objects that importing torch leaves behind costs tens
+    # of milliseconds and lands in one step out of ~25 (measured: one 45 ms step in the first 40).  Everything alive now is
+    # set-up state; freeze it (the collector stays ON for what the steps allocate) -- what a long-running trainer does
+    # too, see INTEGRATION.md.
+    gc.collect()
+    gc.freeze()
     mod.layer_selector.finish_pending()       # deferred selector tail of the last warm-up step: outside the timing
     bucket.wait(all_slots=True)
     # Kernels reported with a roofline object, timed live with HIP events recorded on the stream they are queued on
