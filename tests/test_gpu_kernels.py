@@ -115,7 +115,9 @@ def test_centered_grams_multi(dev, B, N, D, dtype):
     (49, 49, 98, 5), (50, 50, 100, 5), (7, 7, 7, 5), (96, 96, 192, 5), (130, 130, 130, 5),
     # batch < 0: the 4-lanes-per-pair kernel shape, batch > 1000: the 8-lanes one (basd_jacobi_tuning)
     (49, 49, 98, -30), (31, 31, 62, -26), (64, 64, 128, -8), (9, 9, 18, -6), (24, 30, 61, -7),
-    (49, 49, 98, 1030), (31, 31, 62, 1026), (64, 64, 128, 1008), (9, 9, 18, 1006), (24, 30, 61, 1007)])
+    (49, 49, 98, 1030), (31, 31, 62, 1026), (64, 64, 128, 1008), (9, 9, 18, 1006), (24, 30, 61, 1007),
+    # matrices that do not fit LDS: the block path (panels of 16 / 32 / 64 lanes per pair, as wide as LDS allows)
+    (144, 144, 288, 3), (196, 196, 392, 2), (200, 200, 200, 2), (384, 384, 384, 2), (150, 160, 470, 2), (512, 512, 1024, 1)])
 def test_jacobi_lds_invariants(dev, n, rows_dot, rows_tot, batch):
     from basd_amd import ops, _lib
     g = torch.Generator().manual_seed(n)

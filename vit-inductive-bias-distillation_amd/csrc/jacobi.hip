@@ -67,12 +67,17 @@ __device__ __forceinline__ Rot make_rotation(float alpha, float beta, float gamm
 
 template <int LPP>
 __device__ __forceinline__ float pair_allsum(float x) {
-    static_assert(LPP == 4 || LPP == 8 || LPP == 16 || LPP == 64, "a pair is owned by a quad, half a DPP row, a row or a wave");
+    static_assert(LPP == 4 || LPP == 8 || LPP == 16 || LPP == 32 || LPP == 64,
+                  "a pair is owned by a quad, half a DPP row, a row, two rows or a wave");
     if constexpr (LPP == 4 || LPP == 8) {
         x += dpp_get<0xB1>(x);    // quad_perm [1,0,3,2]
         x += dpp_get<0x4E>(x);    // quad_perm [2,3,0,1]
         if constexpr (LPP == 8) x += dpp_get<0x141>(x);   // row_half_mirror
         return x;
+    } else if constexpr (LPP == 32) {
+        x = row16_allsum(x);
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
     } else {
         return LPP == 16 ? row16_allsum(x) : wave64_allsum(x);
     }
@@ -249,18 +254,19 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
 }
 
 // ---------------------------------------------------------------------------
-// Block solver: one launch = one round-robin round over column blocks.
-// grid = (nblk/2, batch), block = 64 * BW threads: one WAVE per column pair (16 waves keep the four SIMDs'
-// issue slots busy; a lone wave per SIMD issues one VALU instruction every 4 cycles instead of every 2).
-// Columns are padded to 64 * EPL rows.  flags[m * max_sweeps + s] != 0 <=> a rotation was applied in sweep s.
+// Block solver: one launch = one round-robin round over column blocks of BW columns.
+// grid = (nblk/2, batch), block = LPP * BW threads: LPP lanes per column pair, BW pairs at a time.  The panel of 2 BW
+// columns is staged in LDS; what a sweep costs is the trips of the matrix through L2 / HBM -- nblk - 1 rounds, each
+// reading and writing every column once -- so the host picks the widest panel that fits (few lanes per pair when the
+// columns are short: 288 rows x 112 columns at cfg-5 is 3 rounds per sweep where one wave per pair and 32 columns
+// took 9).  Columns are padded to LPP * EPL rows.  flags[m * max_sweeps + s] != 0 <=> a rotation was applied in sweep s.
 // ---------------------------------------------------------------------------
-template <int BW, int EPL, int DOT>
-__global__ void __launch_bounds__(64 * BW) jacobi_block_round_kernel(float* __restrict__ W, long batch_stride,
-                                                                     int rows_dot, int rows_tot, int n, int nblk,
-                                                                     int round, int sweep, int max_sweeps,
-                                                                     float tol, int* __restrict__ flags,
-                                                                     int* __restrict__ norm2_bits) {
-    constexpr int LPP = 64;
+template <int EPL, int DOT, int LPP>
+__global__ void __launch_bounds__(1024) jacobi_block_round_kernel(float* __restrict__ W, long batch_stride,
+                                                                  int rows_dot, int rows_tot, int n, int nblk, int BW,
+                                                                  int round, int sweep, int max_sweeps,
+                                                                  float tol, int* __restrict__ flags,
+                                                                  int* __restrict__ norm2_bits) {
     constexpr int LD = LPP * EPL + 2;   // even: 8-byte aligned columns for the paired accesses
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m = blockIdx.y;
@@ -277,7 +283,7 @@ __global__ void __launch_bounds__(64 * BW) jacobi_block_round_kernel(float* __re
     // stage the 2*BW columns (zero-padded rows, zero columns >= n).  The panel is tiny next to the launch's
     // latency budget, so what matters is loads in flight: every thread issues several independent 16-byte
     // loads before the first LDS write.
-    constexpr int NT = LPP * BW;
+    const int NT = LPP * BW;
     const bool padded = rows_tot != LPP * EPL || (bi + 1) * BW > n || (bj + 1) * BW > n;
     if (padded) {
         for (int idx = tid; idx < 2 * BW * LD; idx += NT) lds[idx] = 0.f;
@@ -587,51 +593,90 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
 
     // ---- block path: one launch per round-robin round over blocks of BW columns ----
     BASD_CHECK_ARG(n_arr == nullptr && flags != nullptr);
-    constexpr int BW = 16;
-    int nblk = (n + BW - 1) / BW;
-    nblk = (nblk + 1) & ~1;
-    // per-lane element counts with one wave (64 lanes) per column pair
-    const int dot64 = (rows_dot + 63) / 64, ride64 = (rows_tot - rows_dot + 63) / 64;
-    const int half64 = dot64 > ride64 ? dot64 : ride64;
-    const int epl64 = stacked ? 2 * half64 : dot64;
-    static const int blk_epl[] = {2, 4, 6, 8, 12, 16};
-    int e_blk = 0;
-    for (int e : blk_epl)
-        if (e >= epl64 && (!stacked || e % 4 == 0)) { e_blk = e; break; }
-    if (!e_blk) return BASD_EUNSUPPORTED;                        // more than 1024 (padded) rows
-    const size_t panel_bytes = (size_t)2 * BW * (64 * e_blk + 4) * sizeof(float);
-    if (panel_bytes > BASD_JACOBI_LDS_LIMIT) return BASD_EUNSUPPORTED;
+    // Panel shape: lanes per column pair (64 / 32 / 16), elements per lane, columns per block.  A sweep is nblk - 1
+    // trips of the whole matrix through L2 / HBM, so: the widest panel that fits LDS; ties go to more lanes per pair.
+    struct Shape { int lpp, epl, dot, bw, nblk; };
+    Shape best{0, 0, 0, 0, 1 << 30};
+    // instantiated element counts per lane: `dot` of the stacked shapes (EPL = 2 dot), EPL of the plain ones
+    static const int st64[] = {2, 4, 6, 8, 0}, pl64[] = {2, 4, 6, 8, 12, 16, 0};
+    static const int st32[] = {4, 8, 12, 16, 20, 0}, pl32[] = {4, 8, 12, 16, 20, 0};
+    static const int st16[] = {8, 10, 14, 16, 20, 0}, pl16[] = {8, 10, 14, 16, 20, 28, 32, 0};
+    static const int lpps[] = {64, 32, 16};
+    for (int lpp : lpps) {
+        const int cd = (rows_dot + 2 * lpp - 1) / (2 * lpp), cr = (rows_tot - rows_dot + 2 * lpp - 1) / (2 * lpp);
+        const int need = 2 * (stacked && cr > cd ? cr : cd);
+        const int* q = lpp == 64 ? (stacked ? st64 : pl64) : lpp == 32 ? (stacked ? st32 : pl32) : (stacked ? st16 : pl16);
+        int sel = 0;
+        for (; *q; ++q)
+            if (*q >= need) { sel = *q; break; }
+        if (!sel) continue;
+        const int epl = stacked ? 2 * sel : sel;
+        const size_t col_bytes = sizeof(float) * (size_t)(lpp * epl + 2);
+        int bw = (int)((BASD_JACOBI_LDS_LIMIT - 64) / (2 * (col_bytes + 8)));      // + norm / defect per column
+        if (bw > 1024 / lpp) bw = 1024 / lpp;
+        if (bw > ((n + 1) & ~1)) bw = (n + 1) & ~1;
+        bw &= ~1;
+        if (bw < 2) continue;
+        int nb = (n + bw - 1) / bw;
+        nb = (nb + 1) & ~1;
+        if (nb < best.nblk) best = Shape{lpp, epl, sel, bw, nb};
+    }
+    if (!best.lpp) return BASD_EUNSUPPORTED;                     // columns too long for a two-column panel in LDS
+    const int BW = best.bw, nblk = best.nblk;
+    const size_t panel_bytes = (size_t)2 * BW * (best.lpp * best.epl + 2 + 2) * sizeof(float);
     hipError_t err = hipMemsetAsync(flags, 0, sizeof(int) * (size_t)2 * batch * max_sweeps, stream);
     if (err != hipSuccess) return (int)err;
-#define LAUNCH_BLOCK(E, D)                                                                                       \
+#define LAUNCH_BLOCK(E, D, LP)                                                                                   \
     do {                                                                                                         \
         if (panel_bytes > 48 * 1024)                                                                             \
-            (void)hipFuncSetAttribute((const void*)jacobi_block_round_kernel<BW, E, D>,                          \
+            (void)hipFuncSetAttribute((const void*)jacobi_block_round_kernel<E, D, LP>,                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, BASD_JACOBI_LDS_LIMIT);        \
         for (int s = 0; s < max_sweeps; ++s)                                                                     \
             for (int r = 0; r < nblk - 1; ++r)                                                                   \
-                jacobi_block_round_kernel<BW, E, D><<<dim3(nblk / 2, batch), 64 * BW, panel_bytes, stream>>>(    \
-                    W, batch_stride, rows_dot, rows_tot, n, nblk, r, s, max_sweeps, tol, flags,                  \
+                jacobi_block_round_kernel<E, D, LP><<<dim3(nblk / 2, batch), LP * BW, panel_bytes, stream>>>(    \
+                    W, batch_stride, rows_dot, rows_tot, n, nblk, BW, r, s, max_sweeps, tol, flags,              \
                     flags + (size_t)batch * max_sweeps);                                                         \
     } while (0)
-#define LAUNCH_BLOCK_E(E)                                      \
-    do {                                                       \
-        if (stacked) {                                         \
-            if constexpr ((E) % 4 == 0) LAUNCH_BLOCK(E, (E) / 2); \
-        } else {                                               \
-            LAUNCH_BLOCK(E, E);                                \
-        }                                                      \
+#define LAUNCH_BLOCK_SEL(Q, LP)                      \
+    do {                                             \
+        if (stacked) LAUNCH_BLOCK(2 * (Q), Q, LP);   \
+        else LAUNCH_BLOCK(Q, Q, LP);                 \
     } while (0)
-    switch (e_blk) {
-        case 2: LAUNCH_BLOCK_E(2); break;
-        case 4: LAUNCH_BLOCK_E(4); break;
-        case 6: LAUNCH_BLOCK_E(6); break;
-        case 8: LAUNCH_BLOCK_E(8); break;
-        case 12: LAUNCH_BLOCK_E(12); break;
-        default: LAUNCH_BLOCK_E(16); break;
+    bool launched = true;
+    if (best.lpp == 64) {
+        switch (best.dot) {
+            case 2: LAUNCH_BLOCK_SEL(2, 64); break;
+            case 4: LAUNCH_BLOCK_SEL(4, 64); break;
+            case 6: LAUNCH_BLOCK_SEL(6, 64); break;
+            case 8: LAUNCH_BLOCK_SEL(8, 64); break;
+            case 12: LAUNCH_BLOCK(12, 12, 64); break;
+            case 16: LAUNCH_BLOCK(16, 16, 64); break;
+            default: launched = false; break;
+        }
+    } else if (best.lpp == 32) {
+        switch (best.dot) {
+            case 4: LAUNCH_BLOCK_SEL(4, 32); break;
+            case 8: LAUNCH_BLOCK_SEL(8, 32); break;
+            case 12: LAUNCH_BLOCK_SEL(12, 32); break;
+            case 16: LAUNCH_BLOCK_SEL(16, 32); break;
+            case 20: LAUNCH_BLOCK_SEL(20, 32); break;
+            default: launched = false; break;
+        }
+    } else {
+        switch (best.dot) {
+            case 8: LAUNCH_BLOCK_SEL(8, 16); break;
+            case 10: LAUNCH_BLOCK_SEL(10, 16); break;
+            case 14: LAUNCH_BLOCK_SEL(14, 16); break;
+            case 16: LAUNCH_BLOCK_SEL(16, 16); break;
+            case 20: LAUNCH_BLOCK_SEL(20, 16); break;
+            case 28: LAUNCH_BLOCK(28, 28, 16); break;
+            case 32: LAUNCH_BLOCK(32, 32, 16); break;
+            default: launched = false; break;
+        }
     }
-#undef LAUNCH_BLOCK_E
+#undef LAUNCH_BLOCK_SEL
 #undef LAUNCH_BLOCK
+    if (!launched) return BASD_EUNSUPPORTED;
     colnorm_kernel<<<dim3((n + 3) / 4, batch), 256, 0, stream>>>(W, batch_stride, rows_dot, rows_tot, n, colnorm,
                                                                  colnorm_stride);
     BASD_RETURN_LAST();
