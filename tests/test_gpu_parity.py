@@ -253,6 +253,32 @@ def test_cfg2_full_size(golden):
     assert abs(loss.item() - 2 * ce * geo / (ce + geo)) < 1e-4 * loss.item()
 
 
+def test_observable_only_changes_nothing_observable():
+    """``BASDLoss.observable_only`` (single teacher layer: the student-side selector work the reference does cannot be
+    observed) -- loss, every gradient and ``subspace_ranks`` are bit-identical with and without it, two steps in a row."""
+    shape = synth.CONFIGS["cfg2"]
+    out = []
+    for flag in (False, True):
+        mod = _module(shape, 0.001)
+        mod.observable_only = flag
+        per_step = []
+        for seed in (1234, 99):
+            inp = synth.make_inputs(shape, seed, batch=16, device=DEV, strided=True)
+            leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
+            logits = inp.logits.detach().requires_grad_(True)
+            loss = mod(logits, inp.targets, leaves, inp.teacher, inp.attn)
+            loss.backward()
+            per_step.append((loss.detach().clone(), logits.grad.clone(), [leaves[l].grad.clone() for l in mod.token_layers],
+                             dict(mod.layer_selector.subspace_ranks), mod.layer_selector.log_temperatures.grad))
+        mod.layer_selector.finish_pending()
+        torch.cuda.synchronize()
+        out.append(per_step)
+    for a, b in zip(*out):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[3] == b[3]
+        assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+        assert (a[4] is None or not a[4].any()) and (b[4] is None or not b[4].any())
+
+
 def test_bf16_inputs_cfg5_shapes():
     """cfg-5 (bf16 features): tokens are consumed in place as bf16 and widened inside the kernels; the parity
     target is the fp32 oracle on the same bf16-rounded values (the reference itself has no runnable
