@@ -311,8 +311,16 @@ typedef struct BasdProcrustesArgs {
     float* tr_t; float* nuc; float* loss_b; float* k_prime;
     float* h; float* dx; const float* grad_layers;
     double* g_slabs; long g_splits;     /* nullable / <= 1: teacher Gram unsplit; else g_splits * G*B*n*n doubles of scratch */
+    /* UW-SO combination (combined.py:76-85) inside the call, nullable: uw_ce = the base loss (one fp32 on the device);
+     * uw_out (4 + 2 E floats) receives w_ce, w_geo, total, geo, then E x w_geo / E, then the E per-layer means.  The
+     * student gradients (dx) are then those of `total` for a unit upstream gradient and grad_layers is ignored. */
+    const float* uw_ce; float* uw_out;
 } BasdProcrustesArgs;
 int basd_procrustes_forward_fused(const BasdProcrustesArgs* args, hipStream_t stream);
+
+/* x *= num / den unless the ratio is exactly 1 (then the launch returns at once): the upstream gradient of a loss that
+ * was differentiated for a unit one.  num, den: one fp32 each on the device, den nullable (= 1). */
+int basd_scale_unless_one(float* x, long count, const float* num, const float* den, hipStream_t stream);
 
 /* The base criterion of BASDLoss (combined.py:56) when it is the stock torch.nn.CrossEntropyLoss (mean reduction, no
  * class weights): per-row losses (already divided by the number of rows that are not ignored; loss = their sum) and

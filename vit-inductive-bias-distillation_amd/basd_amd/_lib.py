@@ -34,6 +34,7 @@ SIGNATURES = {
     "basd_tridiag_tuning": [i32, i32, i32, i32, i32, i32],
     "basd_tridiag": [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp],
     "basd_tridiag_ranked": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp, vp],
+    "basd_scale_unless_one": [vp, i64, vp, vp, vp],
     "basd_event_create": [vp],
     "basd_event_destroy": [vp],
     "basd_stream_wait_event": [vp, vp],
@@ -90,6 +91,7 @@ class ProcrustesArgs(C.Structure):
                              "l_all", "W", "sigma", "jflags", "sweeps", "tr_t", "nuc", "loss_b", "k_prime", "h", "dx",
                              "grad_layers", "g_slabs")]
         + [("g_splits", i64)]
+        + [("uw_ce", vp), ("uw_out", vp)]
     )
 
 

@@ -271,7 +271,24 @@ class _SingleTeacherTotal(torch.autograd.Function):
     def forward(ctx, ce, has_cls, zero_param, teachers, attns, *students):
         E = len(students)
         need_bwd = any(s.requires_grad for s in students)
+        ctx.n_students = E
+        ctx.dtypes = [s.dtype for s in students]
+        ctx.zero_shape = None if zero_param is None else (tuple(zero_param.shape), zero_param.dtype)
         ones = ops._device_consts((1.0,) * E, torch.float32, ce.device)
+        # the UW-SO combination inside the library call when the base loss is one fp32 on the device: the student
+        # gradients queued by forward are then FINAL for a unit upstream gradient (no 308 MB scaling pass in backward,
+        # no dozen torch micro-kernels for the weights between the Procrustes kernels and the rank read-back)
+        ctx.final = need_bwd and ce.dtype == torch.float32 and ce.numel() == 1 and ce.is_cuda
+        if ctx.final:
+            pc = ops.procrustes_forward(list(students), teachers, attns, ones.view(-1, 1), has_cls, need_backward=True,
+                                        need_mix_grad=False, uwso_ce=ce.detach().reshape(1))
+            uw = pc.uw
+            geo_layers = uw[4 + E:4 + 2 * E]
+            ctx.unit_grads = pc.dx      # (E, B, N_s, D_s): d total / d student tokens for a unit upstream gradient
+            ctx.applied = None          # upstream gradient the buffer has been scaled by (None: 1)
+            ctx.save_for_backward(uw[:2])
+            ctx.mark_non_differentiable(geo_layers)
+            return uw[2].reshape(()), geo_layers
         pc = ops.procrustes_forward(list(students), teachers, attns, ones.view(-1, 1), has_cls, need_backward=need_bwd,
                                     need_mix_grad=False, grad_layers=ones if need_bwd else None)
         geo_layers = pc.loss_b.mean(dim=1)
@@ -281,9 +298,6 @@ class _SingleTeacherTotal(torch.autograd.Function):
         inv = 1.0 / vals.clamp(min=torch.finfo(ce.dtype).eps)
         w = inv / inv.sum()
         ctx.save_for_backward(w)
-        ctx.n_students = E
-        ctx.dtypes = [s.dtype for s in students]
-        ctx.zero_shape = None if zero_param is None else (tuple(zero_param.shape), zero_param.dtype)
         ctx.mark_non_differentiable(geo_layers)
         return (w * vals).sum(), geo_layers
 
@@ -293,7 +307,18 @@ class _SingleTeacherTotal(torch.autograd.Function):
         (w,) = ctx.saved_tensors
         gw = g * w
         grads = [None] * ctx.n_students
-        if ctx.unit_grads is not None:
+        if ctx.unit_grads is not None and ctx.final:
+            gf = g.detach().float().reshape(1)
+            if ctx.applied is None:
+                # in place; a launch that returns at once for the usual upstream gradient of exactly 1
+                ops.scale_unless_one(ctx.unit_grads, gf)
+                ctx.applied = gf
+                buf = ctx.unit_grads
+            else:
+                # a second backward through a retained graph: the buffer may be aliased by gradients handed out before
+                buf = ctx.unit_grads * (gf / ctx.applied)
+            grads = [buf[i].to(dt) if ctx.needs_input_grad[5 + i] else None for i, dt in enumerate(ctx.dtypes)]
+        elif ctx.unit_grads is not None:
             scale = gw[1] / ctx.n_students
             scaled = ctx.unit_grads * scale         # ONE launch over all layers (they share the upstream scalar)
             grads = [scaled[i].to(dt) if ctx.needs_input_grad[5 + i] else None for i, dt in enumerate(ctx.dtypes)]

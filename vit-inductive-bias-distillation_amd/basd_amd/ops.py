@@ -517,6 +517,7 @@ class ProcrustesContext:
     sweeps: torch.Tensor | None
     mixgrad: dict | None = None   # extra state kept only when the mixing weights need a gradient
     dx: torch.Tensor | None = None   # (E, B, n_s, D_s) student gradients queued with the forward (``grad_layers``)
+    uw: torch.Tensor | None = None   # (4 + 2 E,) UW-SO combination computed inside the call (``uwso_ce``)
 
 
 def _check_common_layout(tensors: list[torch.Tensor], what: str) -> list[torch.Tensor]:
@@ -536,11 +537,15 @@ def _check_common_layout(tensors: list[torch.Tensor], what: str) -> list[torch.T
 def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor], attns: list[torch.Tensor],
                        mix: torch.Tensor, has_cls: bool, *, need_backward: bool = True,
                        want_sweeps: bool = False, need_mix_grad: bool = False,
-                       grad_layers: torch.Tensor | None = None) -> ProcrustesContext:
+                       grad_layers: torch.Tensor | None = None,
+                       uwso_ce: torch.Tensor | None = None) -> ProcrustesContext:
     """students: E tensors (B, N_s, D_s); teachers: L tensors (B, N_t, D_t); attns: L tensors (B, H, A, A);
     mix: (E, L) fp32 mixing weights on device.  Returns per-sample terms for every extraction layer.
     ``grad_layers`` ((E,) fp32 on device): also queue the student-token gradients for these upstream gradients
-    (``ctx.dx``: (E, B, N_s, D_s) fp32).  Everything is queued by ONE library call (basd_procrustes_forward_fused)."""
+    (``ctx.dx``: (E, B, N_s, D_s) fp32).  ``uwso_ce`` (one fp32 on the device, the base loss): the UW-SO combination
+    (combined.py:76-85) is computed inside the call as well -- ``ctx.uw`` = [w_ce, w_geo, total, geo, E x w_geo / E,
+    E per-layer means] -- and ``ctx.dx`` are then the gradients of ``total`` for a unit upstream gradient.
+    Everything is queued by ONE library call (basd_procrustes_forward_fused)."""
     import ctypes
     E, L = len(students), len(teachers)
     students = [as_supported(s) for s in students]
@@ -593,11 +598,15 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
         sweeps = ints[-EB:]
         sweeps.zero_()
     raw = torch.empty((G, B, n_a), **f32) if need_mix_grad else None
-    h = dx = None
-    if grad_layers is not None:
+    h = dx = uw = None
+    if uwso_ce is not None:
+        assert uwso_ce.dtype == torch.float32 and uwso_ce.numel() == 1 and uwso_ce.device == dev
+        uw = torch.empty((4 + 2 * E,), **f32)
+    if grad_layers is not None or uw is not None:
         h = torch.empty((E, B, n, d_s), **f32)
         dx = torch.empty((E, B, n_s, d_s), **f32)
-        grad_layers = grad_layers.contiguous().float()
+        if grad_layers is not None:
+            grad_layers = grad_layers.contiguous().float()
 
     args = _lib.ProcrustesArgs()
     host_ptrs = (ctypes.c_void_p * E)(*[s.data_ptr() for s in students])
@@ -628,6 +637,7 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     args.sigma, args.jflags, args.sweeps, args.k_prime = sigma.data_ptr(), ints.data_ptr(), _ptr(sweeps), _ptr(k_prime)
     args.h, args.dx, args.grad_layers = _ptr(h), _ptr(dx), _ptr(grad_layers)
     args.g_slabs, args.g_splits = _ptr(g_slabs), g_splits
+    args.uw_ce, args.uw_out = _ptr(uwso_ce), _ptr(uw)
     gpu_mark("procrustes_begin")
     _lib.call("basd_procrustes_forward_fused", ctypes.addressof(args), _stream())
     gpu_mark("procrustes_end")
@@ -640,7 +650,14 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
                        attns=attns, tok_tab=_ptr_table(teachers), att_tab=_ptr_table(attns), has_cls=has_cls, n_a=n_a,
                        n=n, n_s=n_s, gather=gt, student_taps=tp, attn_taps=atp)
     return ProcrustesContext(omega, mu_s, a_prime, k_prime, terms[0], terms[1], terms[2], terms[3], sweeps, mixgrad,
-                             dx)
+                             dx, uw)
+
+
+def scale_unless_one(x: torch.Tensor, num: torch.Tensor, den: torch.Tensor | None = None) -> None:
+    """x *= num / den in place unless the ratio is exactly 1 (the launch then returns at once)."""
+    _require_cuda(x, num)
+    assert x.dtype == torch.float32 and x.is_contiguous() and num.dtype == torch.float32 and num.numel() == 1
+    _lib.call("basd_scale_unless_one", x.data_ptr(), x.numel(), num.data_ptr(), _ptr(den), _stream())
 
 
 def procrustes_student_grads(students: list[torch.Tensor], ctx: ProcrustesContext, grad_layers: torch.Tensor,

@@ -5,7 +5,67 @@
 #include "basd_common.h"
 #include "../../include/basd_hip.h"
 
+namespace basd {
+
+// combined.py:76-85 on the device: per-layer means of loss_b (E, B), their mean, the UW-SO weights of (ce, geo) from the
+// DETACHED values, the total.  One workgroup; means accumulated in fp64 in a fixed order.
+__global__ void __launch_bounds__(256) uwso_combine_kernel(const float* __restrict__ ce, const float* __restrict__ loss_b,
+                                                           int E, int B, float* __restrict__ out) {
+    __shared__ double red[4];
+    __shared__ double geo_sum;
+    const int tid = threadIdx.x;
+    if (tid == 0) geo_sum = 0.;
+    for (int e = 0; e < E; ++e) {
+        double acc = 0.;
+        for (int b = tid; b < B; b += 256) acc += (double)loss_b[(long)e * B + b];
+        for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            const float layer = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)B);
+            out[4 + E + e] = layer;
+            geo_sum += (double)layer;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float c = ce[0], geo = (float)(geo_sum / (double)E);
+        const float eps = 1.1920929e-7f;                       // torch.finfo(float32).eps
+        const float i0 = 1.f / fmaxf(c, eps), i1 = 1.f / fmaxf(geo, eps);
+        const float w0 = i0 / (i0 + i1), w1 = i1 / (i0 + i1);
+        out[0] = w0;
+        out[1] = w1;
+        out[2] = w0 * c + w1 * geo;
+        out[3] = geo;
+        for (int e = 0; e < E; ++e) out[4 + e] = w1 / (float)E;
+    }
+}
+
+__global__ void __launch_bounds__(256) scale_unless_one_kernel(float* __restrict__ x, long count4, long count,
+                                                               const float* __restrict__ num,
+                                                               const float* __restrict__ den) {
+    const float f = den ? num[0] / den[0] : num[0];
+    if (f == 1.f) return;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < count4) {
+        float4 v = ((float4*)x)[i];
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        ((float4*)x)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(count - 4 * count4)) x[4 * count4 + threadIdx.x] *= f;
+}
+
+}  // namespace basd
+
 extern "C" {
+
+int basd_scale_unless_one(float* x, long count, const float* num, const float* den, hipStream_t stream) {
+    BASD_CHECK_ARG(x && num && count > 0 && ((uintptr_t)x & 15) == 0);
+    const long count4 = count / 4;
+    basd::scale_unless_one_kernel<<<(unsigned)((count4 + 255) / 256 + (count4 == 0)), 256, 0, stream>>>(x, count4, count, num, den);
+    BASD_RETURN_LAST();
+}
 
 // relational.py:22-50 for all extraction layers against the (mixed) teacher, forward and -- optionally -- the student
 // gradients for given upstream gradients; see BasdProcrustesArgs in include/basd_hip.h.
@@ -62,13 +122,20 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
     BASD_TRY(basd_procrustes_finalize(a->W, 2 * nn, a->sigma, n, n_s, EB, GB, a->g_all + (long)EB * nn, nn, a->omega,
                                       a->tap0, a->tap1, a->lam, a->tr_part, slabs, a->tr_s, a->tr_t, a->nuc,
                                       a->loss_b, a->k_prime, st));
+    // combined.py:76-85: the UW-SO weights and the total, on the device (the student gradients below are then final)
+    const float* grad_layers = a->grad_layers;
+    if (a->uw_ce) {
+        BASD_CHECK_ARG(a->uw_out != nullptr);
+        basd::uwso_combine_kernel<<<1, 256, 0, st>>>(a->uw_ce, a->loss_b, E, B, a->uw_out);
+        grad_layers = a->uw_out + 4;
+    }
     // student gradients for the upstream gradients grad_layers (E floats on the device): H = K' A', then one pass
     if (a->dx) {
-        BASD_CHECK_ARG(a->k_prime && a->h && a->grad_layers);
+        BASD_CHECK_ARG(a->k_prime && a->h && grad_layers);
         BASD_TRY(basd_gemm_tn(a->k_prime, a->a_prime, BASD_DTYPE_F32, 0, n, 1, nn, 0, d_s, 1, (long)n * d_s, 1 << 30, n,
                               n, d_s, EB, nullptr, nullptr, 1, nullptr, a->h, d_s, (long)n * d_s, 1.f, st));
         BASD_TRY(basd_student_grad_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s, a->omega,
-                                         om_stride, a->mu_s, a->h, a->tap0, a->tap1, a->lam, a->grad_layers,
+                                         om_stride, a->mu_s, a->h, a->tap0, a->tap1, a->lam, grad_layers,
                                          2.0f / (float)B, a->dx, nullptr, nullptr, st));
     }
 #undef BASD_TRY
