@@ -127,7 +127,9 @@ long basd_tridiag_workspace_bytes(int n, int batch);
 /* `work`: basd_tridiag_workspace_bytes(n, batch) bytes of 16-byte aligned device scratch.
  * Two stages: the trailing block of order <= 256 is factored in the registers of ONE CU per matrix (n <= 256: the
  * whole factorisation -- no workgroup waits for another); for n > 256 the first n - 256 steps run with the matrix
- * shared by up to 16 workgroups that exchange one 16-byte granule per row and step through `work`.  Its last 32
+ * shared by up to 16 workgroups that exchange one 16-byte granule per row and step through `work` (all workgroups of
+ * that launch must be resident together: at most half of what an occupancy query says the device holds of the kernel,
+ * and never more than 128; beyond that the member count per matrix shrinks, down to 1 = no exchange).  Its last 32
  * bytes hold a status word that is non-zero afterwards if a workgroup of the shared stage gave up waiting for its
  * partners, and a trace of the first give-up (step + 1, row, member | matrix << 8, tag seen, tag wanted). */
 int basd_tridiag(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
@@ -146,7 +148,8 @@ int basd_tridiag_ranked(float* a, long a_batch_stride, int n, int batch, float* 
  * BASD_TRIDIAG_{MEMBERS,PAD,LAG,THREADS,TAIL} environment variables, read ONCE when the library is loaded -- no
  * entry point calls getenv).  Negative = keep; reset != 0 restores the load-time values first.
  * members: workgroups per matrix in the shared stage; pad: workgroup-id padding between matrices; lag: member that
- * sleeps every step; threads: per member; tail: 0 = shared stage for the whole factorisation. */
+ * sleeps every step; threads: per member; tail: 0 = shared stage for the whole factorisation, 1 = the two-barrier
+ * register-resident tail kernel (default), 2 = its four-barrier first form (kept for comparison tests). */
 int basd_tridiag_tuning(int members, int pad, int lag, int threads, int tail, int reset);
 
 /* All eigenvalues (descending) of the tridiagonals by Sturm-sequence bisection. */
