@@ -105,14 +105,17 @@ __device__ __forceinline__ int rotate_pair(float* __restrict__ cp, float* __rest
                                             float* __restrict__ devq) {
     // lane gl owns the row pairs (2 gl, 2 gl + 1) + 2 LPP i: 8-byte LDS accesses and packed fp32 math
     static_assert(EPL % 2 == 0 && DOT % 2 == 0, "row chunks come in pairs");
-    constexpr int H = EPL / 2;
-    f32x2 x[H], y[H];
+    constexpr int H = EPL / 2, HD = DOT / 2;
+    // the dot rows stay in registers between the dot product and the update; the riding rows (stacked shapes) are
+    // read, rotated and written afterwards, a pair at a time: half the registers of holding both halves (the
+    // Procrustes kernel then fits 64 VGPRs, see jacobi_lds_lowreg_kernel)
+    f32x2 x[HD], y[HD];
     f32x2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < H; ++i) {
+    for (int i = 0; i < HD; ++i) {
         x[i] = *(const f32x2*)(cp + 2 * gl + 2 * LPP * i);
         y[i] = *(const f32x2*)(cq + 2 * gl + 2 * LPP * i);
-        if (2 * i < DOT) acc = __builtin_elementwise_fma(x[i], y[i], acc);
+        acc = __builtin_elementwise_fma(x[i], y[i], acc);
     }
     const float g = pair_allsum<LPP>(acc.x + acc.y);
     const float a = *n2p, b = *n2q;
@@ -122,9 +125,16 @@ __device__ __forceinline__ int rotate_pair(float* __restrict__ cp, float* __rest
     if (!rot.apply) return 0;
     const f32x2 c2 = {rot.c, rot.c}, s2 = {rot.s, rot.s};
 #pragma unroll
-    for (int i = 0; i < H; ++i) {
+    for (int i = 0; i < HD; ++i) {
         *(f32x2*)(cp + 2 * gl + 2 * LPP * i) = __builtin_elementwise_fma(c2, x[i], -(s2 * y[i]));
         *(f32x2*)(cq + 2 * gl + 2 * LPP * i) = __builtin_elementwise_fma(s2, x[i], c2 * y[i]);
+    }
+#pragma unroll
+    for (int i = HD; i < H; ++i) {
+        const f32x2 xr = *(const f32x2*)(cp + 2 * gl + 2 * LPP * i);
+        const f32x2 yr = *(const f32x2*)(cq + 2 * gl + 2 * LPP * i);
+        *(f32x2*)(cp + 2 * gl + 2 * LPP * i) = __builtin_elementwise_fma(c2, xr, -(s2 * yr));
+        *(f32x2*)(cq + 2 * gl + 2 * LPP * i) = __builtin_elementwise_fma(s2, xr, c2 * yr);
     }
     if (gl == 0) {
         *n2p = fmaxf(a - rot.t * g, 0.f);
