@@ -281,11 +281,21 @@ int basd_student_grad_multi(const void* const* x_ptrs, int dtype, long sb, long 
                             int D, const float* omega, long omega_e_stride, const float* mu, const float* h,
                             const int* tap0, const int* tap1, const float* lam, const float* scale_ptr,
                             float scale_const, float* dx, const float* tnorm2, float* gomega, hipStream_t stream);
+/* H = K' A' (basd_gemm_tn) and basd_student_grad_multi in ONE launch for cores of n_t <= 64 tokens: each workgroup
+ * forms its 64-feature slab of H in LDS (K' through the scalar cache) and streams the sample's token rows once, so H
+ * never goes to memory.  k_prime (E, B, n_t, n_t) as basd_procrustes_finalize writes it (symmetric), a_prime
+ * (E, B, n_t, D).  Returns BASD_EUNSUPPORTED for larger cores or rows that are not 16-byte aligned: use the two-call
+ * form (autograd of relational.py:36-50 either way). */
+int basd_student_grad_fused(const void* const* x_ptrs, int dtype, long sb, long sn, int E, int B, int n_s, int n_t,
+                            int D, int ptrs_16B_aligned, const float* omega, long omega_e_stride, const float* mu,
+                            const float* k_prime, const float* a_prime, const int* tap0, const int* tap1,
+                            const float* lam, const float* scale_ptr, float scale_const, float* dx,
+                            hipStream_t stream);
 
 /* The whole forward of relational.py:22-50 for E extraction layers against the (mixed) teacher -- and, when `dx` is
  * set, the student-token gradients for the upstream gradients `grad_layers` -- queued by ONE call: the launches of
  * basd_token_weights, basd_teacher_center, basd_student_project(_multi), basd_gram_f64 x2, basd_chol_f64,
- * basd_stack_product, basd_jacobi_onesided, basd_procrustes_finalize [, basd_gemm_tn, basd_student_grad_multi] in
+ * basd_stack_product, basd_jacobi_onesided, basd_procrustes_finalize [, basd_student_grad_fused or basd_gemm_tn + basd_student_grad_multi] in
  * that order (a dozen FFI calls from Python cost several times the launches themselves, and that host time sat in
  * front of the caller's stream).  All fields are 8 bytes wide; pointers are device memory except student_host_ptrs.
  *   G = 1: the teacher side is shared by all layers (one teacher layer: mixing weights exactly 1), else G = E.

@@ -468,3 +468,50 @@ def test_fused_cross_entropy_matches_torch(dev, soft, eps, dtype):
     (lb * 1.7).backward()
     ref = b.grad
     assert ((a.grad.float() - ref).abs().max() / ref.abs().max()).item() < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("side_s, side_t, d_s, E, B, dtype", [
+    (14, 7, 384, 2, 3, torch.float32),      # cfg-2's core: 49 tokens, 13 rows of H per wave
+    (14, 7, 200, 1, 2, torch.bfloat16),     # last slab partly outside D; bf16 rows
+    (4, 4, 64, 1, 2, torch.float32),        # no interpolation, 16 tokens (4 rows per wave)
+    (8, 8, 104, 2, 2, torch.float32),       # 64 tokens: the largest core the kernel takes
+    (6, 3, 64, 1, 2, torch.float32),        # 9 tokens: waves 2 and 3 recompute rows of their neighbours
+    (10, 5, 48, 3, 2, torch.float32),       # 25 tokens
+])
+def test_student_grad_fused_forms_h_in_the_kernel(dev, side_s, side_t, d_s, E, B, dtype):
+    """basd_student_grad_fused (H = K' A' formed per workgroup, never stored) against an fp64 evaluation of
+    dX = g_e (2/B) w_s ((x_s - mu) - interp(K' A')_s) from the forward's own K', A', mu, omega (autograd of
+    relational.py:36-50), and against the two-launch form."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(side_s * 1000 + side_t * 10 + E)
+    n_s, n_t, d_t, H = side_s * side_s, side_t * side_t, 96, 2
+    students = [torch.randn(B, n_s, d_s, generator=g).to(dev).to(dtype) for _ in range(E)]
+    teacher = torch.randn(B, n_t, d_t, generator=g).to(dev)
+    attn = torch.rand(B, H, n_t, n_t, generator=g).to(dev)
+    ctx = ops.procrustes_forward(students, [teacher], [attn], torch.ones(E, 1, device=dev), False)
+    grad_layers = torch.rand(E, generator=g).to(dev) + 0.5
+    grads = ops.procrustes_student_grads(students, ctx, grad_layers)
+    n = min(n_s, n_t)
+    assert n <= 64
+    tp = ops.taps(n, n_s, dev)
+    Hm = torch.matmul(ctx.k_prime.double(), ctx.a_prime.double())                   # (E, B, n, d)
+    if tp is not None:
+        lam = tp.lam.double()[None, None, :, None]
+        tgt = (1 - lam) * Hm[:, :, tp.tap0.long()] + lam * Hm[:, :, tp.tap1.long()]
+    else:
+        tgt = Hm
+    x = torch.stack([s.double() for s in students])
+    om = ctx.omega.double().expand(E, B, n_s)
+    ref = grad_layers.double()[:, None, None, None] * (2.0 / B) * om[..., None] * ((x - ctx.mu_s.double()[:, :, None]) - tgt)
+    for e in range(E):
+        assert _rel(grads[e], ref[e]) < 1e-5, (e, _rel(grads[e], ref[e]))
+    # the two-launch form (GEMM + gradient kernel) gives the same tensor up to fp32 rounding of H
+    h = torch.matmul(ctx.k_prime, ctx.a_prime).contiguous()
+    dx2 = torch.empty((E, B, n_s, d_s), device=dev, dtype=torch.float32)
+    xs = [s.contiguous() for s in students]
+    t0, t1, lm = (tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr()) if tp else (None, None, None)
+    ops._lib.call("basd_student_grad_multi", ops._ptr_table(xs).data_ptr(), ops._dtype_code(xs[0]), xs[0].stride(0),
+                  xs[0].stride(1), E, B, n_s, n, d_s, ctx.omega.data_ptr(), 0, ctx.mu_s.data_ptr(), h.data_ptr(), t0, t1,
+                  lm, grad_layers.data_ptr(), 2.0 / B, dx2.data_ptr(), None, None, ops._stream())
+    torch.cuda.synchronize()
+    assert _rel(torch.stack(grads), dx2) < 1e-5

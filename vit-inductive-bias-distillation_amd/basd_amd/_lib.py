@@ -62,6 +62,8 @@ SIGNATURES = {
                                    vp, vp, vp],
     "basd_student_grad_multi": [vp, i32, i64, i64, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, f32, vp,
                                 vp, vp, vp],
+    "basd_student_grad_fused": [vp, i32, i64, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp,
+                                f32, vp, vp],
     "basd_procrustes_forward_fused": [vp, vp],
     "basd_resample_tokens": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "basd_resample_tokens_adjoint": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
@@ -94,6 +96,8 @@ class ProcrustesArgs(C.Structure):
         + [("uw_ce", vp), ("uw_out", vp)]
     )
 
+
+EINVAL, EUNSUPPORTED = -1, -2        # BASD_EINVAL / BASD_EUNSUPPORTED of include/basd_hip.h
 
 # sizing helpers declared `long` in include/basd_hip.h
 LONG_RESULTS = {"basd_tridiag_workspace_bytes"}

@@ -671,17 +671,28 @@ def procrustes_student_grads(students: list[torch.Tensor], ctx: ProcrustesContex
     tp = taps(n, n_s, dev)
     t0, t1, lam = (tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr()) if tp else (None, None, None)
     st = _stream()
+    grad_layers = grad_layers.contiguous().float()
+    xs = [as_supported(x) for x in students]
+    xs = _check_common_layout([x if x.stride(2) == 1 else x.contiguous() for x in xs], "student token tensors")
+    dx = torch.empty((E, B, n_s, d_s), device=dev, dtype=torch.float32)
+    shared = ctx.omega.shape[0] == 1
+    if tnorm2 is None and n <= 64:
+        # small cores: H = K' A' formed inside the gradient kernel (never stored)
+        status = getattr(_lib.load(), "basd_student_grad_fused")(
+            _ptr_table(xs).data_ptr(), _dtype_code(xs[0]), xs[0].stride(0), xs[0].stride(1), E, B, n_s, n, d_s,
+            int(all(x.data_ptr() % 16 == 0 for x in xs)), ctx.omega.data_ptr(), 0 if shared else B * n_s,
+            ctx.mu_s.data_ptr(), ctx.k_prime.data_ptr(), ctx.a_prime.data_ptr(), t0, t1, lam, grad_layers.data_ptr(),
+            2.0 / B, dx.data_ptr(), st)
+        if status == 0:
+            return list(dx.unbind(0))
+        if status != _lib.EUNSUPPORTED:
+            raise RuntimeError(f"basd_student_grad_fused failed with status {status}")
     # H = K' A' per (layer, sample): K' is symmetric, so this is the TN contraction
     kp = ctx.k_prime.view(E * B, n, n)
     ap = ctx.a_prime.view(E * B, n, d_s)
     h = gemm_tn(kp[0], ap[0], batch=E * B, a_batch_stride=n * n, b_batch_stride=n * d_s, krows=n, m_cols=n,
                 n_cols=d_s, split=False).view(E, B, n, d_s)
-    grad_layers = grad_layers.contiguous().float()
-    xs = [as_supported(x) for x in students]
-    xs = _check_common_layout([x if x.stride(2) == 1 else x.contiguous() for x in xs], "student token tensors")
-    dx = torch.empty((E, B, n_s, d_s), device=dev, dtype=torch.float32)
     gomega = torch.empty((E, B, n_s), device=dev, dtype=torch.float32) if tnorm2 is not None else None
-    shared = ctx.omega.shape[0] == 1
     _lib.call("basd_student_grad_multi", _ptr_table(xs).data_ptr(), _dtype_code(xs[0]), xs[0].stride(0),
               xs[0].stride(1), E, B, n_s, n, d_s, ctx.omega.data_ptr(), 0 if shared else B * n_s, ctx.mu_s.data_ptr(),
               h.data_ptr(), t0, t1, lam, grad_layers.data_ptr(), 2.0 / B, dx.data_ptr(), _ptr(tnorm2), _ptr(gomega), st)

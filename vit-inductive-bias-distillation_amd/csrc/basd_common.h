@@ -29,6 +29,13 @@ constexpr int kWave = 64;
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(__hip_bfloat16 x) { return __bfloat162float(x); }
+// Pointers read out of a device pointer table are generic, and loads through them are flat_load (they wait on the LDS
+// counter as well): kernels that take such a table cast the table entry to global memory and load through these.
+#define BASD_GLOBAL_AS __attribute__((address_space(1)))
+__device__ __forceinline__ float ldg_f32(const BASD_GLOBAL_AS float* p) { return *p; }
+__device__ __forceinline__ float ldg_f32(const BASD_GLOBAL_AS __hip_bfloat16* p) {
+    return __uint_as_float((unsigned)*(const BASD_GLOBAL_AS unsigned short*)p << 16);
+}
 
 // Reduce over a power-of-two group of `width` adjacent lanes (width <= 64).
 template <typename T>

@@ -11,24 +11,27 @@ namespace basd {
 // DETACHED values, the total.  One workgroup; means accumulated in fp64 in a fixed order.
 __global__ void __launch_bounds__(256) uwso_combine_kernel(const float* __restrict__ ce, const float* __restrict__ loss_b,
                                                            int E, int B, float* __restrict__ out) {
-    __shared__ double red[4];
-    __shared__ double geo_sum;
+    constexpr int CH = 32;                  // layers per pass: one barrier per pass, not two per layer
+    __shared__ double red[CH][4];
     const int tid = threadIdx.x;
-    if (tid == 0) geo_sum = 0.;
-    for (int e = 0; e < E; ++e) {
-        double acc = 0.;
-        for (int b = tid; b < B; b += 256) acc += (double)loss_b[(long)e * B + b];
-        for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            const float layer = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)B);
-            out[4 + E + e] = layer;
-            geo_sum += (double)layer;
+    double geo_sum = 0.;                    // thread 0 only
+    for (int e0 = 0; e0 < E; e0 += CH) {
+        const int ne = E - e0 < CH ? E - e0 : CH;
+        for (int e = 0; e < ne; ++e) {
+            double acc = 0.;
+            for (int b = tid; b < B; b += 256) acc += (double)loss_b[(long)(e0 + e) * B + b];
+            for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            if ((tid & 63) == 0) red[e][tid >> 6] = acc;
         }
+        __syncthreads();
+        if (tid == 0)
+            for (int e = 0; e < ne; ++e) {
+                const float layer = (float)(((red[e][0] + red[e][1]) + (red[e][2] + red[e][3])) / (double)B);
+                out[4 + E + e0 + e] = layer;
+                geo_sum += (double)layer;
+            }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid == 0) {
         const float c = ce[0], geo = (float)(geo_sum / (double)E);
         const float eps = 1.1920929e-7f;                       // torch.finfo(float32).eps
@@ -132,6 +135,10 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
     // student gradients for the upstream gradients grad_layers (E floats on the device): H = K' A', then one pass
     if (a->dx) {
         BASD_CHECK_ARG(a->k_prime && a->h && grad_layers);
+        rc = basd_student_grad_fused(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s,
+                                     (int)a->s_aligned, a->omega, om_stride, a->mu_s, a->k_prime, a->a_prime, a->tap0,
+                                     a->tap1, a->lam, grad_layers, 2.0f / (float)B, a->dx, st);
+        if (rc != BASD_EUNSUPPORTED) return rc;
         BASD_TRY(basd_gemm_tn(a->k_prime, a->a_prime, BASD_DTYPE_F32, 0, n, 1, nn, 0, d_s, 1, (long)n * d_s, 1 << 30, n,
                               n, d_s, EB, nullptr, nullptr, 1, nullptr, a->h, d_s, (long)n * d_s, 1.f, st));
         BASD_TRY(basd_student_grad_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s, a->omega,

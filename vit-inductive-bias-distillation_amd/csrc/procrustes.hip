@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) token_weights_kernel(const void* const* _
             for (int h = 0; h < H; ++h) {
                 float m = 0.f;
                 for (int l = 0; l < L; ++l)
-                    m += mix[l] * to_f32(((const T*)attn_ptrs[l])[b * sb + h * sh + (long)(1 + j) * sk]);
+                    m += mix[l] * ldg_f32((const BASD_GLOBAL_AS T*)attn_ptrs[l] + (b * sb + h * sh + (long)(1 + j) * sk));
                 acc += m;
             }
             acc /= (float)H;
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) token_weights_kernel(const void* const* _
                 for (int q = 0; q < A; ++q) {
                     float m = 0.f;
                     for (int l = 0; l < L; ++l)
-                        m += mix[l] * to_f32(((const T*)attn_ptrs[l])[b * sb + h * sh + q * sq + (long)j * sk]);
+                        m += mix[l] * ldg_f32((const BASD_GLOBAL_AS T*)attn_ptrs[l] + (b * sb + h * sh + q * sq + (long)j * sk));
                     acc += m;
                 }
             acc /= (float)(H * A);
@@ -177,6 +177,17 @@ __global__ void __launch_bounds__(256) student_project_kernel(const T* __restric
 // sweeps (weighted mean, trace, projection) then read LDS instead of pulling 256-byte row segments through L2
 // four or five times.  Needs 16-byte aligned rows and (n_s * 65) floats of LDS (n_s <= ~600).
 __device__ __forceinline__ float4 ld4f(const float* p) { return *(const float4*)p; }
+typedef float native_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned native_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld4f(const BASD_GLOBAL_AS float* p) {
+    const native_f32x4 v = *(const BASD_GLOBAL_AS native_f32x4*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 ld4f(const BASD_GLOBAL_AS __hip_bfloat16* p) {
+    const native_u32x2 v = *(const BASD_GLOBAL_AS native_u32x2*)p;
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xffff0000u));
+}
 __device__ __forceinline__ float4 ld4f(const __hip_bfloat16* p) {
     const uint2 v = *(const uint2*)p;
     return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
@@ -280,7 +291,7 @@ __global__ void __launch_bounds__(256) student_project_v4_kernel(const void* con
     const int b = blockIdx.y, e = blockIdx.z, B = gridDim.y, d0 = blockIdx.x * SP_W, tid = threadIdx.x;
     const int fq = tid & 7, rg = tid >> 3, c4 = 4 * fq;
     const bool live = d0 + c4 < D;         // D % 4 == 0: the quad is inside or outside
-    const T* Xb = (const T*)x_ptrs[e] + (long)b * sb + d0;
+    const BASD_GLOBAL_AS T* Xb = (const BASD_GLOBAL_AS T*)x_ptrs[e] + (long)b * sb + d0;
     const float* om = omega + (long)e * omega_e_stride + (long)b * n_s;
     for (int n = tid; n < n_s; n += 256) {
         const float wn = om[n];
@@ -381,15 +392,15 @@ __global__ void __launch_bounds__(256) teacher_center_kernel(const void* const* 
                 const long r0 = g0[j], r1 = g1[j];
                 float a0 = 0.f, a1 = 0.f;
                 for (int l = 0; l < L; ++l) {
-                    const T* p = (const T*)tok_ptrs[l];
-                    a0 = fmaf(mix[l], to_f32(p[off + r0 * sn]), a0);
-                    a1 = fmaf(mix[l], to_f32(p[off + r1 * sn]), a1);
+                    const BASD_GLOBAL_AS T* p = (const BASD_GLOBAL_AS T*)tok_ptrs[l];
+                    a0 = fmaf(mix[l], ldg_f32(p + (off + r0 * sn)), a0);
+                    a1 = fmaf(mix[l], ldg_f32(p + (off + r1 * sn)), a1);
                 }
                 const float l1 = glam[j];
                 v = (1.f - l1) * a0 + l1 * a1;
             } else {
                 for (int l = 0; l < L; ++l)
-                    v = fmaf(mix[l], to_f32(((const T*)tok_ptrs[l])[off + (long)j * sn]), v);
+                    v = fmaf(mix[l], ldg_f32((const BASD_GLOBAL_AS T*)tok_ptrs[l] + (off + (long)j * sn)), v);
             }
         }
         tile[j * 65 + dd] = v;
@@ -737,6 +748,92 @@ __global__ void __launch_bounds__(128) student_grad_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------
+// Backward, student tokens, with H = K' A' formed in the workgroup instead of by a GEMM launch: one workgroup per
+// (64-feature slab, sample, layer) stages its A' slab in LDS, wave g computes rows [RP g, RP g + RP) of the H slab with
+// K' read through the scalar cache (K' is bit-symmetric, so row k serves as column k: the coefficients of one k are
+// contiguous and wave-uniform), parks H in LDS and streams the sample's n_s token rows once.  Removes the H round trip
+// (77 MB written + 77 MB read at cfg-2) and a launch whose 49-row GEMMs left two thirds of each MFMA tile empty.
+// RP <= n_t <= 4 RP; 16-byte aligned token rows; D % 4 == 0.
+// ---------------------------------------------------------------------------
+constexpr int SG_W = 64;          // slab width in features
+constexpr int SG_LD = SG_W + 4;   // row stride of the H slab in LDS
+template <typename T, int RP>
+__global__ void __launch_bounds__(256) student_grad_fused_kernel(
+    const void* const* __restrict__ x_ptrs, long sb, long sn, int n_s, int n_t, int D, const float* __restrict__ omega,
+    long omega_e_stride, const float* __restrict__ mu, const float* __restrict__ Kp, const float* __restrict__ Ap,
+    const int* __restrict__ tap0, const int* __restrict__ tap1, const float* __restrict__ lam,
+    const float* __restrict__ scale_ptr, float scale_const, float* __restrict__ dX) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* as = sm;                        // n_t x 64: A' slab
+    float* hs = sm + (long)n_t * SG_W;     // n_t x 68: H slab
+    const int by = blockIdx.y, e = blockIdx.z, d0 = blockIdx.x * SG_W, tid = threadIdx.x;
+    const long b = (long)e * gridDim.y + by;
+    const int q4 = 4 * (tid & 15);
+    const bool live = d0 + q4 < D;
+    const float* A = Ap + b * n_t * D + d0;
+    for (int k = tid >> 4; k < n_t; k += 16) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) v = *(const float4*)(A + (long)k * D + q4);
+        *(float4*)(as + k * SG_W + q4) = v;
+    }
+    __syncthreads();
+    {
+        // rows [i0, i0 + RP): the last waves step back so that their RP coefficients stay inside row k of K' (they
+        // recompute rows of the wave before them and store the same values)
+        const int g = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
+        const int i0 = RP * g < n_t - RP ? RP * g : n_t - RP;
+        const float* K = Kp + b * n_t * n_t + i0;
+        float acc[RP];
+#pragma unroll
+        for (int r = 0; r < RP; ++r) acc[r] = 0.f;
+        for (int k = 0; k < n_t; ++k) {
+            const float a = as[k * SG_W + c];
+            const float* Kk = K + (long)k * n_t;
+#pragma unroll
+            for (int r = 0; r < RP; ++r) acc[r] = fmaf(Kk[r], a, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RP; ++r) hs[(i0 + r) * SG_LD + c] = acc[r];
+    }
+    __syncthreads();
+    const BASD_GLOBAL_AS T* Xb = (const BASD_GLOBAL_AS T*)x_ptrs[e] + (long)by * sb + d0 + q4;
+    const float* om = omega + (long)e * omega_e_stride + (long)by * n_s;
+    float* out = dX + b * n_s * D + d0 + q4;
+    const float sc = scale_ptr[e] * scale_const;
+    float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) m4 = *(const float4*)(mu + b * D + d0 + q4);
+    if (!live) return;
+    for (int s0 = tid >> 4; s0 < n_s; s0 += 64) {
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 16 * u;
+            if (s < n_s) x[u] = ld4f(Xb + (long)s * sn);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 16 * u;
+            if (s >= n_s) break;
+            int i0 = s, i1 = s;
+            float l1 = 0.f;
+            if (tap0) {
+                i0 = tap0[s];
+                i1 = tap1[s];
+                l1 = lam[s];
+            }
+            const float coef = sc * om[s];
+            const float4 h0 = *(const float4*)(hs + i0 * SG_LD + q4), h1 = *(const float4*)(hs + i1 * SG_LD + q4);
+            float4 o;
+            o.x = coef * ((x[u].x - m4.x) - ((1.f - l1) * h0.x + l1 * h1.x));
+            o.y = coef * ((x[u].y - m4.y) - ((1.f - l1) * h0.y + l1 * h1.y));
+            o.z = coef * ((x[u].z - m4.z) - ((1.f - l1) * h0.z + l1 * h1.z));
+            o.w = coef * ((x[u].w - m4.w) - ((1.f - l1) * h0.w + l1 * h1.w));
+            *(float4*)(out + (long)s * D) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Stand-alone token-count interpolation (reference combined.py:9-14), used by the public
 // `_align_token_count`; the fused loss path never materialises this tensor.
 // grid = (n_out, B), block = 128.   adjoint != 0: scatter-free transpose (out is n_in rows).
@@ -963,6 +1060,45 @@ int basd_student_grad_multi(const void* const* x_ptrs, int dtype, long sb, long 
         student_grad_kernel<__hip_bfloat16><<<grid, 128, 0, stream>>>(nullptr, x_ptrs, sb, sn, n_s, n_t, D, omega, omega_e_stride, mu, h, tap0, tap1, lam, scale_ptr, scale_const, dx, tnorm2, gomega);
     else
         return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+// basd_gemm_tn (H = K' A') + basd_student_grad_multi in one launch, for cores of up to 64 teacher tokens (see the
+// kernel).  k_prime (E, B, n_t, n_t) as basd_procrustes_finalize writes it, a_prime (E, B, n_t, D).  Returns
+// BASD_EUNSUPPORTED where it does not apply (larger cores, rows not 16-byte aligned): call the two-launch form.
+int basd_student_grad_fused(const void* const* x_ptrs, int dtype, long sb, long sn, int E, int B, int n_s, int n_t,
+                            int D, int ptrs_16B_aligned, const float* omega, long omega_e_stride, const float* mu,
+                            const float* k_prime, const float* a_prime, const int* tap0, const int* tap1,
+                            const float* lam, const float* scale_ptr, float scale_const, float* dx,
+                            hipStream_t stream) {
+    BASD_CHECK_ARG(x_ptrs && omega && mu && k_prime && a_prime && scale_ptr && dx && E > 0 && B > 0 && n_s > 0 && n_t > 0 && D > 0);
+    BASD_CHECK_ARG((n_t == n_s) == (tap0 == nullptr));
+    BASD_CHECK_ARG(E <= 65535 && B <= 65535);
+    const int esz = dtype == BASD_DTYPE_F32 ? 4 : 2;
+    const bool ok = ptrs_16B_aligned && n_t <= 64 && D % 4 == 0 && (sb * esz) % 16 == 0 && (sn * esz) % 16 == 0 &&
+                    (esz == 4 || D % 8 == 0) && ((uintptr_t)a_prime & 15) == 0 && ((uintptr_t)mu & 15) == 0 &&
+                    ((uintptr_t)dx & 15) == 0;
+    if (!ok) return BASD_EUNSUPPORTED;
+    if (n_t < 4) return BASD_EUNSUPPORTED;
+    const int rp = (n_t + 3) / 4;
+    const size_t lds = sizeof(float) * (size_t)n_t * (SG_W + SG_LD);
+    const dim3 grid((D + SG_W - 1) / SG_W, B, E);
+#define LAUNCH_SGF(TY, RP)                                                                                           \
+    student_grad_fused_kernel<TY, RP><<<grid, 256, lds, stream>>>(x_ptrs, sb, sn, n_s, n_t, D, omega, omega_e_stride, mu, \
+                                                                  k_prime, a_prime, tap0, tap1, lam, scale_ptr,      \
+                                                                  scale_const, dx)
+#define LAUNCH_SGF_T(TY)                 \
+    do {                                 \
+        if (rp <= 4) LAUNCH_SGF(TY, 4);  \
+        else if (rp <= 8) LAUNCH_SGF(TY, 8);  \
+        else if (rp <= 13) LAUNCH_SGF(TY, 13); \
+        else LAUNCH_SGF(TY, 16);         \
+    } while (0)
+    if (dtype == BASD_DTYPE_F32) LAUNCH_SGF_T(float);
+    else if (dtype == BASD_DTYPE_BF16) LAUNCH_SGF_T(__hip_bfloat16);
+    else return BASD_EINVAL;
+#undef LAUNCH_SGF_T
+#undef LAUNCH_SGF
     BASD_RETURN_LAST();
 }
 
