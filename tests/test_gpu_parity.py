@@ -500,3 +500,43 @@ def test_give_up_degrades_to_one_member(golden, tag, monkeypatch):
         loss.backward()
     finally:
         _lib.call("basd_tridiag_tuning", -1, -1, -1, -1, -1, 1)
+
+
+@pytest.mark.parametrize("n_s,n_t,d_s,d_t,cls", [
+    (256, 256, 320, 384, False),     # 255 < D: cores of full rank 255, Grams past one workgroup's tile list
+    (576, 576, 96, 128, True),       # a ViT teacher at 384 x 384: 576 tokens on both sides, cores of rank 96
+    (324, 576, 64, 96, True),        # finer teacher grid resampled to 324 student tokens
+    (400, 225, 48, 160, False),      # coarser teacher: the core grid is the teacher's 225 tokens
+])
+def test_cores_past_lds_vs_fp64(n_s, n_t, d_s, d_t, cls):
+    """min(N_s, N_t) > 196: the Gram tile list is cut into chunks, the Cholesky factor lives in global memory
+    (panels in LDS), the SVD takes the block path and K' a tiled kernel.  Per-sample terms and the student gradient
+    against an fp64 evaluation of relational.py:36-50 (autograd through svdvals)."""
+    from basd_amd import ops
+    gen = torch.Generator().manual_seed(n_s + 3 * n_t)
+    B = 2
+    s = synth.structured(gen, B, n_s, d_s, 8) + 0.5
+    t = synth.structured(gen, B, n_t, d_t, 6) - 0.25
+    a = n_t + (1 if cls else 0)
+    attn = torch.softmax(torch.randn(B, 2, a, a, generator=gen), dim=-1)
+    w = O.token_weights(attn, cls, n_s).double()
+    t_al = O.resample_tokens(t, n_s).double()
+    s64 = s.double().requires_grad_(True)
+    w3 = w.unsqueeze(-1)
+    s_w = w3.sqrt() * (s64 - (w3 * s64).sum(1, keepdim=True))
+    t_w = w3.sqrt() * (t_al - (w3 * t_al).sum(1, keepdim=True))
+    tr_s, tr_t = s_w.square().sum((1, 2)), t_w.square().sum((1, 2))
+    nuc = torch.linalg.svdvals(torch.bmm(s_w.transpose(1, 2), t_w)).sum(-1)
+    ref_b = tr_s + tr_t - 2 * nuc
+    ref_b.mean().backward()
+    sd = s.to(DEV)
+    pc = ops.procrustes_forward([sd], [t.to(DEV)], [attn.to(DEV)], torch.ones(1, 1, device=DEV), cls,
+                                want_sweeps=True)
+    assert int(pc.sweeps.max()) < ops.MAX_SWEEPS
+    np.testing.assert_allclose(pc.tr_s[0].cpu().numpy(), tr_s.detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(pc.tr_t[0].cpu().numpy(), tr_t.detach().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(pc.nuc[0].cpu().numpy(), nuc.detach().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(pc.loss_b[0].cpu().numpy(), ref_b.detach().numpy(), rtol=1e-4)
+    grads = ops.procrustes_student_grads([sd], pc, torch.ones(1, device=DEV))
+    err = (grads[0].double().cpu() - s64.grad).norm() / s64.grad.norm()
+    assert err < 1e-4, err

@@ -608,7 +608,7 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
     struct Shape { int lpp, epl, dot, bw, nblk; };
     Shape best{0, 0, 0, 0, 1 << 30};
     // instantiated element counts per lane: `dot` of the stacked shapes (EPL = 2 dot), EPL of the plain ones
-    static const int st64[] = {2, 4, 6, 8, 0}, pl64[] = {2, 4, 6, 8, 12, 16, 0};
+    static const int st64[] = {2, 4, 6, 8, 10, 12, 16, 0}, pl64[] = {2, 4, 6, 8, 12, 16, 0};
     static const int st32[] = {4, 8, 12, 16, 20, 0}, pl32[] = {4, 8, 12, 16, 20, 0};
     static const int st16[] = {8, 10, 14, 16, 20, 0}, pl16[] = {8, 10, 14, 16, 20, 28, 32, 0};
     static const int lpps[] = {64, 32, 16};
@@ -659,8 +659,9 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
             case 4: LAUNCH_BLOCK_SEL(4, 64); break;
             case 6: LAUNCH_BLOCK_SEL(6, 64); break;
             case 8: LAUNCH_BLOCK_SEL(8, 64); break;
-            case 12: LAUNCH_BLOCK(12, 12, 64); break;
-            case 16: LAUNCH_BLOCK(16, 16, 64); break;
+            case 10: LAUNCH_BLOCK(20, 10, 64); break;      // stacked cores of 577..640 rows (576 tokens)
+            case 12: LAUNCH_BLOCK_SEL(12, 64); break;
+            case 16: LAUNCH_BLOCK_SEL(16, 64); break;
             default: launched = false; break;
         }
     } else if (best.lpp == 32) {

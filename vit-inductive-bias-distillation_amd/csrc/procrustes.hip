@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(1024) gram_f64_kernel(const float* __restrict_
     int ti[G64_TPW], tj[G64_TPW];
 #pragma unroll
     for (int t = 0; t < G64_TPW; ++t) {
-        const int lin = wave + t * nw;
+        const int lin = wave + (t + (int)blockIdx.z * G64_TPW) * nw;      // blockIdx.z: chunk of the tile list (n > 240)
         int r = 0;
         if (lin < ntiles) {
             r = (int)((sqrtf(8.f * lin + 1.f) - 1.f) * 0.5f);
@@ -518,6 +518,26 @@ __global__ void __launch_bounds__(256) gram_f64_reduce_kernel(const double* __re
     G[i] = acc;
 }
 
+// Launch shape of gram_f64_kernel: up to 16 waves x G64_TPW tiles per workgroup; past that (n > 240) the tile list is
+// cut into chunks, one workgroup each (every chunk stages all rows of a D-chunk: n <= ~1100 by LDS).
+static bool gram_f64_shape(int n, int* waves, int* chunks, size_t* lds) {
+    const int nt = (n + 15) / 16, ntiles = nt * (nt + 1) / 2;
+    int w = (ntiles + G64_TPW - 1) / G64_TPW;
+    if (w < 4) w = ntiles < 4 ? ntiles : 4;
+    int c = 1;
+    if (w > 16) {
+        c = (ntiles + 16 * G64_TPW - 1) / (16 * G64_TPW);
+        w = 16;
+    }
+    *waves = w;
+    *chunks = c;
+    *lds = sizeof(float) * (size_t)nt * 16 * G64_LD;
+    if (*lds > 156 * 1024) return false;
+    if (*lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)gram_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // fp64 Cholesky of symmetric PSD matrices (possibly singular): G = L L^T, packed in LDS.
 // grid = batch, block = 256..1024.  A pivot below n*1e-15*max_diag zeroes its column.
@@ -574,6 +594,99 @@ __global__ void __launch_bounds__(1024) chol_f64_kernel(const double* __restrict
     for (int idx = tid; idx < n * n; idx += nthr) {
         const int i = idx / n, j = idx - i * n;
         Lm[idx] = i >= j ? a[pk(i, j, n)] : 0.;
+    }
+}
+
+// The same factorisation for matrices past LDS (n > ~200, e.g. a ViT teacher at 384 x 384: 576 tokens): left-looking by
+// panels of CB_NB columns.  L lives in global memory (Lout, written and re-read by this workgroup only); the current
+// panel -- rows j0..n-1 of CB_NB columns -- is accumulated in registers (thread (row group, column): rows rg + 64 r),
+// parked in LDS and factored there column by column with the pivot rule of chol_f64_kernel.
+// grid = batch, block = 1024; n <= 64 * CB_MAXR.
+constexpr int CB_NB = 16, CB_KC = 64, CB_MAXR = 16;
+__global__ void __launch_bounds__(1024) chol_f64_blocked_kernel(const double* __restrict__ G, long g_batch_stride, int n,
+                                                                double* __restrict__ Lout, long l_batch_stride) {
+    extern __shared__ __attribute__((aligned(16))) double sm64[];
+    double* panel = sm64;                               // (n - j0) x CB_NB, row-major
+    double* lj = panel + (size_t)n * CB_NB;             // CB_NB x (CB_KC + 1): rows j0.. of L, columns k0..
+    __shared__ double red[16];
+    __shared__ double lrow[CB_NB];
+    __shared__ double sh_piv;
+    const int m = blockIdx.x, tid = threadIdx.x, c = tid & (CB_NB - 1), rg = tid / CB_NB;
+    const double* Gm = G + (long)m * g_batch_stride;
+    double* Lm = Lout + (long)m * l_batch_stride;
+    double dmax = 0.;
+    for (int i = tid; i < n; i += 1024) dmax = fmax(dmax, Gm[(long)i * n + i]);
+    for (int s2 = 32; s2 > 0; s2 >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, s2, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = dmax;
+    __syncthreads();
+    dmax = 0.;
+    for (int i = 0; i < 16; ++i) dmax = fmax(dmax, red[i]);
+    const double thr = dmax * (double)n * 1e-15;
+    for (long idx = tid; idx < (long)n * n; idx += 1024) {          // strictly upper triangle
+        const int i = (int)(idx / n), j = (int)(idx - (long)i * n);
+        if (j > i) Lm[idx] = 0.;
+    }
+    for (int j0 = 0; j0 < n; j0 += CB_NB) {
+        const int nb = n - j0 < CB_NB ? n - j0 : CB_NB, rows = n - j0;
+        double acc[CB_MAXR];
+#pragma unroll
+        for (int r = 0; r < CB_MAXR; ++r) {
+            const int i = j0 + rg + 64 * r;
+            acc[r] = (i < n && c < nb) ? Gm[(long)i * n + j0 + c] : 0.;
+        }
+        for (int k0 = 0; k0 < j0; k0 += CB_KC) {
+            const int kc = j0 - k0 < CB_KC ? j0 - k0 : CB_KC;
+            __syncthreads();
+            for (int idx = tid; idx < CB_NB * CB_KC; idx += 1024) {
+                const int cc = idx / CB_KC, k = idx - cc * CB_KC;
+                lj[cc * (CB_KC + 1) + k] = (cc < nb && k < kc) ? Lm[(long)(j0 + cc) * n + k0 + k] : 0.;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < CB_MAXR; ++r) {
+                const int i = j0 + rg + 64 * r;
+                if (i < n) {
+                    const double* Li = Lm + (long)i * n + k0;
+                    double a2 = acc[r];
+                    for (int k = 0; k < kc; ++k) a2 = fma(-Li[k], lj[c * (CB_KC + 1) + k], a2);
+                    acc[r] = a2;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CB_MAXR; ++r) {
+            const int ii = rg + 64 * r;
+            if (ii < rows) panel[ii * CB_NB + c] = acc[r];
+        }
+        __syncthreads();
+        for (int jj = 0; jj < nb; ++jj) {
+            if (tid == 0) {
+                const double d = panel[jj * CB_NB + jj];
+                sh_piv = d > thr ? sqrt(d) : 0.;
+            }
+            __syncthreads();
+            const double piv = sh_piv;
+            const double inv = piv > 0. ? 1. / piv : 0.;
+            for (int ii = jj + tid; ii < rows; ii += 1024) {
+                const double v = (ii == jj) ? piv : panel[ii * CB_NB + jj] * inv;
+                panel[ii * CB_NB + jj] = v;
+                if (ii < CB_NB) lrow[ii] = v;
+            }
+            __syncthreads();
+            if (piv > 0.) {
+                for (int idx = tid; idx < (rows - jj - 1) * CB_NB; idx += 1024) {
+                    const int ii = jj + 1 + idx / CB_NB, cc = idx & (CB_NB - 1);
+                    if (cc > jj && cc < nb && cc <= ii) panel[ii * CB_NB + cc] -= panel[ii * CB_NB + jj] * lrow[cc];
+                }
+            }
+            __syncthreads();
+        }
+        for (int idx = tid; idx < rows * CB_NB; idx += 1024) {
+            const int ii = idx / CB_NB, cc = idx & (CB_NB - 1);
+            if (cc < nb) Lm[(long)(j0 + ii) * n + j0 + cc] = ii >= cc ? panel[idx] : 0.;
+        }
+        __syncthreads();    // the rows just written are read back (by other threads) for the next panel
     }
 }
 
@@ -694,6 +807,50 @@ __global__ void __launch_bounds__(256) procrustes_finalize_kernel(
             for (int j = 0; j < n; ++j) acc = fmaf(Yh[j * n + r], Yh[j * n + c], acc);
             K[idx] = acc;
         }
+    }
+}
+
+// K' = Y diag(sigma^+) Y^T for cores past the LDS-resident finalize kernel (n > 199): 32 x 32 output tiles.
+// grid = (ceil(n/32), ceil(n/32), batch), block = 256.  Same truncation rule as procrustes_finalize_kernel.
+__global__ void __launch_bounds__(256) kprime_tiled_kernel(const float* __restrict__ W, long w_batch_stride,
+                                                           const float* __restrict__ sigma, int n,
+                                                           float* __restrict__ Kp) {
+    __shared__ float ya[32][33], yb[32][33];      // [j][row]
+    __shared__ float red[4];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tid = threadIdx.x;
+    const float* sg = sigma + (long)b * n;
+    float smax = 0.f;
+    for (int j = tid; j < n; j += 256) smax = fmaxf(smax, sg[j]);
+    smax = wave_max(smax);
+    if ((tid & 63) == 0) red[tid >> 6] = smax;
+    __syncthreads();
+    smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float thr = smax * (float)n * 1.1920929e-7f;
+    const float* Wb = W + (long)b * w_batch_stride;
+    const int tx = tid & 31, ty = tid >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < n; j0 += 32) {
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int jj = idx >> 5, rr = idx & 31, j = j0 + jj;
+            float sc = 0.f;
+            if (j < n && sg[j] > thr) sc = sqrtf(1.f / sg[j]);
+            ya[jj][rr] = (j < n && r0 + rr < n) ? Wb[(long)j * 2 * n + n + r0 + rr] * sc : 0.f;
+            yb[jj][rr] = (j < n && c0 + rr < n) ? Wb[(long)j * 2 * n + n + c0 + rr] * sc : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int jj = 0; jj < 32; ++jj) {
+            const float bv = yb[jj][tx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(ya[jj][ty + 8 * i], bv, acc[i]);
+        }
+    }
+    float* K = Kp + (long)b * n * n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < n && c < n) K[(long)r * n + c] = acc[i];
     }
 }
 
@@ -961,12 +1118,10 @@ int basd_gram_f64(const float* p, long p_batch_stride, int n, int D, int batch, 
                   hipStream_t stream) {
     BASD_CHECK_ARG(p && g && n > 0 && D > 0 && batch > 0);
     BASD_CHECK_ARG(((uintptr_t)p & 15) == 0 && D % 4 == 0 && p_batch_stride % 4 == 0);
-    const int nt = (n + 15) / 16, ntiles = nt * (nt + 1) / 2;
-    int waves = (ntiles + G64_TPW - 1) / G64_TPW;
-    if (waves < 4) waves = ntiles < 4 ? ntiles : 4;
-    if (waves > 16) return BASD_EUNSUPPORTED;   // n > 240
-    const size_t lds = sizeof(float) * (size_t)nt * 16 * G64_LD;
-    gram_f64_kernel<<<batch, 64 * waves, lds, stream>>>(p, p_batch_stride, n, D, g, g_batch_stride, 0);
+    int waves, chunks;
+    size_t lds;
+    if (!gram_f64_shape(n, &waves, &chunks, &lds)) return BASD_EUNSUPPORTED;
+    gram_f64_kernel<<<dim3(batch, 1, chunks), 64 * waves, lds, stream>>>(p, p_batch_stride, n, D, g, g_batch_stride, 0);
     BASD_RETURN_LAST();
 }
 
@@ -977,13 +1132,11 @@ int basd_gram_f64_split(const float* p, long p_batch_stride, int n, int D, int b
                         double* g, hipStream_t stream) {
     BASD_CHECK_ARG(p && g && slabs && n > 0 && D > 0 && batch > 0 && splits >= 1 && splits <= 64);
     BASD_CHECK_ARG(((uintptr_t)p & 15) == 0 && D % 4 == 0 && p_batch_stride % 4 == 0);
-    const int nt = (n + 15) / 16, ntiles = nt * (nt + 1) / 2;
-    int waves = (ntiles + G64_TPW - 1) / G64_TPW;
-    if (waves < 4) waves = ntiles < 4 ? ntiles : 4;
-    if (waves > 16) return BASD_EUNSUPPORTED;   // n > 240
-    const size_t lds = sizeof(float) * (size_t)nt * 16 * G64_LD;
+    int waves, chunks;
+    size_t lds;
+    if (!gram_f64_shape(n, &waves, &chunks, &lds)) return BASD_EUNSUPPORTED;
     const long count = (long)batch * n * n;
-    gram_f64_kernel<<<dim3(batch, splits), 64 * waves, lds, stream>>>(p, p_batch_stride, n, D, slabs, (long)n * n, count);
+    gram_f64_kernel<<<dim3(batch, splits, chunks), 64 * waves, lds, stream>>>(p, p_batch_stride, n, D, slabs, (long)n * n, count);
     gram_f64_reduce_kernel<<<(unsigned)((count + 255) / 256), 256, 0, stream>>>(slabs, count, splits, count, g);
     BASD_RETURN_LAST();
 }
@@ -992,7 +1145,14 @@ int basd_chol_f64(const double* g, long g_batch_stride, int n, int batch, double
                   hipStream_t stream) {
     BASD_CHECK_ARG(g && l && n > 0 && batch > 0);
     const size_t lds = sizeof(double) * ((size_t)n * (n + 1) / 2 + n);
-    if (lds > 158 * 1024) return BASD_EUNSUPPORTED;
+    if (lds > 158 * 1024) {
+        // past LDS: panels of the factor in LDS, the factor itself in global memory
+        if (n > 64 * CB_MAXR) return BASD_EUNSUPPORTED;
+        const size_t lds_b = sizeof(double) * ((size_t)n * CB_NB + (size_t)CB_NB * (CB_KC + 1));
+        (void)hipFuncSetAttribute((const void*)chol_f64_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        chol_f64_blocked_kernel<<<batch, 1024, lds_b, stream>>>(g, g_batch_stride, n, l, l_batch_stride);
+        BASD_RETURN_LAST();
+    }
     (void)hipFuncSetAttribute((const void*)chol_f64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
     const int threads = n >= 128 ? 1024 : n >= 64 ? 512 : 256;
     chol_f64_kernel<<<batch, threads, lds, stream>>>(g, g_batch_stride, n, l, l_batch_stride);
@@ -1019,10 +1179,17 @@ int basd_procrustes_finalize(const float* w, long w_batch_stride, const float* s
                              float* tr_t, float* nuc, float* loss, float* k_prime, hipStream_t stream) {
     BASD_CHECK_ARG(w && sigma && gb && omega && tr_s_part && tr_s && tr_t && nuc && loss && n > 0 && batch > 0 && tr_slabs > 0);
     BASD_CHECK_ARG(t_period > 0);
-    const size_t lds = sizeof(float) * ((size_t)n + (k_prime ? (size_t)n * n : 0));
+    size_t lds = sizeof(float) * ((size_t)n + (k_prime ? (size_t)n * n : 0));
+    const bool tiled = lds > 156 * 1024;       // K' past LDS: the per-sample terms here, K' by a tiled kernel
+    if (tiled) lds = sizeof(float) * (size_t)n;
     if (lds > 156 * 1024) return BASD_EUNSUPPORTED;
     (void)hipFuncSetAttribute((const void*)procrustes_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    procrustes_finalize_kernel<<<batch, 256, lds, stream>>>(w, w_batch_stride, sigma, n, n_s, gb, g_batch_stride, omega, tap0, tap1, lam, tr_s_part, tr_slabs, tr_s, tr_t, nuc, loss, k_prime, t_period);
+    procrustes_finalize_kernel<<<batch, 256, lds, stream>>>(w, w_batch_stride, sigma, n, n_s, gb, g_batch_stride, omega, tap0, tap1, lam, tr_s_part, tr_slabs, tr_s, tr_t, nuc, loss, tiled ? nullptr : k_prime, t_period);
+    if (tiled) {
+        BASD_CHECK_ARG(batch <= 65535);
+        const int nt = (n + 31) / 32;
+        kprime_tiled_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(w, w_batch_stride, sigma, n, k_prime);
+    }
     BASD_RETURN_LAST();
 }
 
