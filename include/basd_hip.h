@@ -358,6 +358,12 @@ int basd_teacher_factor(const float* w, long w_batch_stride, const float* sigma,
                         const double* la, const double* gb, long g_batch_stride, const float* omega,
                         const int* tap0, const int* tap1, const float* lam, const int* range0, const int* range1,
                         float* kt, float* tnorm2, hipStream_t stream);
+/* The same for cores past LDS (basd_teacher_factor returns BASD_EUNSUPPORTED for n > 199): both contractions tiled,
+ * Z = L_a U Sigma^-1/2 through z_scratch, (batch, n, n) floats of device scratch. */
+int basd_teacher_factor_tiled(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
+                              const double* la, const double* gb, long g_batch_stride, const float* omega,
+                              const int* tap0, const int* tap1, const float* lam, const int* range0, const int* range1,
+                              float* kt, float* tnorm2, float* z_scratch, hipStream_t stream);
 
 /* partial[e][b][l] = <R[e][b], teacher layer l on the core grid>: d loss / d mix_l through the tokens
  * (layer_selector.py:111). */

@@ -540,3 +540,86 @@ def test_cores_past_lds_vs_fp64(n_s, n_t, d_s, d_t, cls):
     grads = ops.procrustes_student_grads([sd], pc, torch.ones(1, device=DEV))
     err = (grads[0].double().cpu() - s64.grad).norm() / s64.grad.norm()
     assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("n,d_s,d_t,cls", [(256, 320, 384, False), (576, 64, 96, True)])
+def test_relational_all_gradients_past_lds_vs_fp64(n, d_s, d_t, cls):
+    """geometric_relational_loss at token grids past the LDS-resident kernels (ViT teacher at 384 x 384: 576 tokens):
+    loss and gradients w.r.t. student tokens, teacher tokens and attention against fp64 autograd of
+    relational.py:18-50 (the teacher-side factor takes the tiled kernels there)."""
+    from basd_amd.losses import geometric_relational_loss
+    gen = torch.Generator().manual_seed(5 * n + d_s)
+    B = 2
+    s = synth.structured(gen, B, n, d_s, 8) + 0.5
+    t = synth.structured(gen, B, n, d_t, 6) - 0.25
+    a = n + (1 if cls else 0)
+    attn = torch.softmax(torch.randn(B, 2, a, a, generator=gen), dim=-1)
+    s64, t64, a64 = (x.double().requires_grad_(True) for x in (s, t, attn))
+    w = (a64[:, :, 0, 1:].mean(1) if cls else a64.mean((1, 2)))
+    w = w / w.sum(-1, keepdim=True)
+    w3 = w.unsqueeze(-1)
+    s_w = w3.sqrt() * (s64 - (w3 * s64).sum(1, keepdim=True))
+    t_w = w3.sqrt() * (t64 - (w3 * t64).sum(1, keepdim=True))
+    ref = (s_w.square().sum((1, 2)) + t_w.square().sum((1, 2))
+           - 2 * torch.linalg.svdvals(torch.bmm(s_w.transpose(1, 2), t_w)).sum(-1)).mean()
+    rs, rt, ra = torch.autograd.grad(ref, [s64, t64, a64])
+    sd, td, ad = (x.to(DEV).requires_grad_(True) for x in (s, t, attn))
+    loss = geometric_relational_loss(sd, td, ad, has_cls_token=cls)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+    gs, gt, ga = torch.autograd.grad(loss, [sd, td, ad])
+    for got, want, name in ((gs, rs, "student"), (gt, rt, "teacher"), (ga, ra, "attn")):
+        err = ((got.double().cpu() - want).norm() / want.norm()).item()
+        assert err < (2e-3 if name == "attn" else 2e-4), (name, err)
+
+
+def test_teacher_factor_tiled_matches_lds_kernel():
+    """The tiled teacher-side factor (cores past LDS) against the LDS-resident kernel on cores that fit both."""
+    from basd_amd import ops
+    gen = torch.Generator().manual_seed(91)
+    B, n_s, n_t, d_s, d_t = 3, 196, 100, 72, 80
+    s = synth.structured(gen, B, n_s, d_s, 8).to(DEV)
+    t = synth.structured(gen, B, n_t, d_t, 6).to(DEV)
+    attn = torch.softmax(torch.randn(B, 2, n_t, n_t, generator=gen), dim=-1).to(DEV)
+    pc = ops.procrustes_forward([s], [t], [attn], torch.ones(1, 1, device=DEV), False, need_mix_grad=True)
+    kt, tn = ops.procrustes_teacher_factor(pc)
+    mg = pc.mixgrad
+    n = mg["n"]
+    tp = mg["student_taps"]
+    kt2, tn2 = torch.empty_like(kt), torch.empty_like(tn)
+    scratch = torch.empty((B, n, n), device=DEV)
+    ops._lib.call("basd_teacher_factor_tiled", mg["W"].data_ptr(), 2 * n * n, mg["sigma"].data_ptr(), n, n_s, B,
+                  mg["l_a"].data_ptr(), mg["g_b"].data_ptr(), n * n, mg["omega_e"].data_ptr(), tp.tap0.data_ptr(),
+                  tp.tap1.data_ptr(), tp.lam.data_ptr(), tp.range0.data_ptr(), tp.range1.data_ptr(), kt2.data_ptr(),
+                  tn2.data_ptr(), scratch.data_ptr(), ops._stream())
+    torch.cuda.synchronize()
+    assert torch.equal(tn, tn2)
+    err = ((kt - kt2).norm() / kt.norm()).item()
+    assert err < 1e-5, err
+
+
+def test_module_with_a_576_token_vit_teacher_vs_oracle():
+    """BASDLoss end to end with a multi-layer ViT teacher at 384 x 384 (576 tokens on both sides, a shape the
+    round-1 build refused): ranks, mixing weights and loss against the CPU oracle, student / temperature gradients
+    against the oracle's autograd (multi-layer tolerance: the route through the principal angles)."""
+    shape = synth.LossShape("vit-384", 3, 576, 64, 12, 576, 96, 3, 2, True, 10, points=2, r_s=8, r_t=6)
+    mod = _module(shape, 0.0)
+    inp = synth.make_inputs(shape, 77)
+    sel = mod.layer_selector
+    st = O.SelectorState(sel.proj_s.detach().cpu(), sel.proj_t.detach().cpu(),
+                         sel.log_temperatures.detach().cpu().clone().requires_grad_(True))
+    ref_leaves = {k: v.clone().requires_grad_(True) for k, v in inp.student.items()}
+    ref, trace = O.basd_forward(st, torch.nn.CrossEntropyLoss(), mod.token_layers, shape.n_s, True, inp.logits,
+                                inp.targets, ref_leaves, inp.teacher, inp.attn)
+    ref.backward()
+    dev_in = synth.make_inputs(shape, 77, device=DEV)
+    leaves = {k: v.requires_grad_(True) for k, v in dev_in.student.items()}
+    loss = mod(dev_in.logits, dev_in.targets, leaves, dev_in.teacher, dev_in.attn)
+    assert {k: sel.subspace_ranks[k] for k in sorted(inp.teacher)} == dict(trace.selector.ranks)
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+    loss.backward()
+    for l in mod.token_layers:
+        want = ref_leaves[l].grad
+        err = ((leaves[l].grad.cpu() - want).norm() / want.norm()).item()
+        assert err < 2e-3, (l, err)
+    np.testing.assert_allclose(sel.log_temperatures.grad.cpu().numpy(), st.log_temperatures.grad.numpy(),
+                               rtol=5e-3, atol=1e-7)

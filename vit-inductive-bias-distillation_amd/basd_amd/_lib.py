@@ -69,6 +69,7 @@ SIGNATURES = {
     "basd_resample_tokens_adjoint": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_student_grad": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp],
     "basd_teacher_factor": [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "basd_teacher_factor_tiled": [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "basd_mix_grad_tokens": [vp, vp, i32, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "basd_token_weight_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, i64, i32,
                               i32, i32, vp, vp, vp],

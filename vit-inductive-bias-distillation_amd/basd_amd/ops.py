@@ -711,9 +711,14 @@ def procrustes_teacher_factor(ctx: ProcrustesContext) -> tuple[torch.Tensor, tor
     r0, r1 = (tp.range0.data_ptr(), tp.range1.data_ptr()) if tp else (None, None)
     kt = torch.empty((E * B, n, n), device=dev, dtype=torch.float32)
     tnorm2 = torch.empty((E, B, n_s), device=dev, dtype=torch.float32)
-    _lib.call("basd_teacher_factor", mg["W"].data_ptr(), 2 * n * n, mg["sigma"].data_ptr(), n, n_s, E * B,
-              mg["l_a"].data_ptr(), mg["g_b"].data_ptr(), n * n, mg["omega_e"].data_ptr(), t0, t1, lam, r0, r1,
-              kt.data_ptr(), tnorm2.data_ptr(), _stream())
+    common = (mg["W"].data_ptr(), 2 * n * n, mg["sigma"].data_ptr(), n, n_s, E * B, mg["l_a"].data_ptr(),
+              mg["g_b"].data_ptr(), n * n, mg["omega_e"].data_ptr(), t0, t1, lam, r0, r1, kt.data_ptr(),
+              tnorm2.data_ptr())
+    if 4 * (n + n * n) <= 156 * 1024:
+        _lib.call("basd_teacher_factor", *common, _stream())
+    else:                                             # cores past LDS: tiled, Z through scratch
+        scratch = torch.empty((E * B, n, n), device=dev, dtype=torch.float32)
+        _lib.call("basd_teacher_factor_tiled", *common, scratch.data_ptr(), _stream())
     return kt, tnorm2
 
 

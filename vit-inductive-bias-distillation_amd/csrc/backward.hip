@@ -81,6 +81,116 @@ __global__ void __launch_bounds__(256) teacher_factor_kernel(
     }
 }
 
+// The same for cores past LDS (n > 199): Z = L_a (U Sigma) Sigma^-1.5 goes through a scratch array (batch, n, n) in
+// global memory, both contractions are tiled 32 x 32.
+//   teacher_z_tiled_kernel:  Zs[c * n + a] = sigma_c^-1.5 sum_{r <= a} L[a][r] W[c][r]      grid = (n/32 (a), n/32 (c), batch)
+//   teacher_kt_tiled_kernel: Kt[a][b] = Q[a][b] - sum_c Zs[c][a] Zs[c][b]                   grid = (n/32 (b), n/32 (a), batch)
+__global__ void __launch_bounds__(256) teacher_z_tiled_kernel(const float* __restrict__ W, long w_batch_stride,
+                                                              const float* __restrict__ sigma, int n,
+                                                              const double* __restrict__ La, long g_batch_stride,
+                                                              float* __restrict__ Z) {
+    __shared__ float lt[32][33], wt[32][33];      // lt[a][r], wt[c][r]
+    __shared__ float red[4];
+    const int b = blockIdx.z, a0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tid = threadIdx.x;
+    const float* sg = sigma + (long)b * n;
+    float smax = 0.f;
+    for (int j = tid; j < n; j += 256) smax = fmaxf(smax, sg[j]);
+    smax = wave_max(smax);
+    if ((tid & 63) == 0) red[tid >> 6] = smax;
+    __syncthreads();
+    smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float thr = smax * (float)n * 1.1920929e-7f;
+    const float* Wb = W + (long)b * w_batch_stride;
+    const double* L = La + (long)b * g_batch_stride;
+    const int tx = tid & 31, ty = tid >> 5;        // tx: a within the tile, ty + 8 i: c within the tile
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < a0 + 32 && r0 < n; r0 += 32) {      // L is lower triangular: r <= a
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int i = idx >> 5, rr = idx & 31, r = r0 + rr;
+            lt[i][rr] = (a0 + i < n && r <= a0 + i) ? (float)L[(long)(a0 + i) * n + r] : 0.f;
+            wt[i][rr] = (c0 + i < n && r < n) ? Wb[(long)(c0 + i) * 2 * n + r] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) {
+            const float lv = lt[tx][rr];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(lv, wt[ty + 8 * i][rr], acc[i]);
+        }
+    }
+    float* Zb = Z + (long)b * n * n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, a = a0 + tx;
+        if (c < n && a < n) {
+            const float sv = sg[c];
+            Zb[(long)c * n + a] = acc[i] * (sv > thr ? 1.f / (sv * sqrtf(sv)) : 0.f);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) teacher_kt_tiled_kernel(
+    const float* __restrict__ Z, int n, int n_s, const double* __restrict__ Gb, long g_batch_stride,
+    const float* __restrict__ omega, const int* __restrict__ tap0, const int* __restrict__ tap1,
+    const float* __restrict__ lam, const int* __restrict__ range0, const int* __restrict__ range1,
+    float* __restrict__ Kt, float* __restrict__ tnorm2) {
+    __shared__ float za[32][33], zb[32][33];      // [c][a], [c][b]
+    const int b = blockIdx.z, a0 = blockIdx.y * 32, b0 = blockIdx.x * 32, tid = threadIdx.x;
+    const float* Zb = Z + (long)b * n * n;
+    const int tx = tid & 31, ty = tid >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < n; c0 += 32) {
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int cc = idx >> 5, i = idx & 31, c = c0 + cc;
+            za[cc][i] = (c < n && a0 + i < n) ? Zb[(long)c * n + a0 + i] : 0.f;
+            zb[cc][i] = (c < n && b0 + i < n) ? Zb[(long)c * n + b0 + i] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int cc = 0; cc < 32; ++cc) {
+            const float bv = zb[cc][tx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(za[cc][ty + 8 * i], bv, acc[i]);
+        }
+    }
+    const float* w = omega + (long)b * n_s;
+    float* K = Kt + (long)b * n * n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a = a0 + ty + 8 * i, bb = b0 + tx;
+        if (a >= n || bb >= n) continue;
+        float q = 0.f;
+        if (tap0) {
+            const int s0 = max(range0[a], range0[bb]), s1 = min(range1[a], range1[bb]);
+            for (int s = s0; s < s1; ++s) {
+                const float l1 = lam[s];
+                const float ca = (tap0[s] == a ? 1.f - l1 : 0.f) + (tap1[s] == a ? l1 : 0.f);
+                const float cb = (tap0[s] == bb ? 1.f - l1 : 0.f) + (tap1[s] == bb ? l1 : 0.f);
+                q = fmaf(w[s] * ca, cb, q);
+            }
+        } else if (a == bb) {
+            q = w[a];
+        }
+        K[(long)a * n + bb] = q - acc[i];
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        const double* G = Gb + (long)b * g_batch_stride;
+        for (int s = tid; s < n_s; s += 256) {
+            double v;
+            if (tap0) {
+                const int i0 = tap0[s], i1 = tap1[s];
+                const double l1 = (double)lam[s], l0 = 1. - l1;
+                v = l0 * l0 * G[(long)i0 * n + i0] + 2. * l0 * l1 * G[(long)i0 * n + i1] + l1 * l1 * G[(long)i1 * n + i1];
+            } else {
+                v = G[(long)s * n + s];
+            }
+            tnorm2[(long)b * n_s + s] = (float)v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // partial[e][b][l] = < R[e][b] , That_l[b] >   (R = (Q - K'') T_c on the core grid of n tokens;
 // That_l = teacher layer l on that grid: gathered with (g0, g1, glam) when the teacher grid is finer).
@@ -315,6 +425,20 @@ int basd_teacher_factor(const float* w, long w_batch_stride, const float* sigma,
         (void)hipFuncSetAttribute((const void*)teacher_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     teacher_factor_kernel<<<batch, 256, lds, stream>>>(w, w_batch_stride, sigma, n, n_s, la, gb, g_batch_stride, omega,
                                                        tap0, tap1, lam, range0, range1, kt, tnorm2);
+    BASD_RETURN_LAST();
+}
+
+// basd_teacher_factor for cores past LDS: z_scratch (batch, n, n) floats of device scratch.
+int basd_teacher_factor_tiled(const float* w, long w_batch_stride, const float* sigma, int n, int n_s, int batch,
+                              const double* la, const double* gb, long g_batch_stride, const float* omega,
+                              const int* tap0, const int* tap1, const float* lam, const int* range0, const int* range1,
+                              float* kt, float* tnorm2, float* z_scratch, hipStream_t stream) {
+    BASD_CHECK_ARG(w && sigma && la && gb && omega && kt && tnorm2 && z_scratch && n > 0 && n_s > 0 && batch > 0);
+    BASD_CHECK_ARG(batch <= 65535);
+    const int nt = (n + 31) / 32;
+    teacher_z_tiled_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(w, w_batch_stride, sigma, n, la, g_batch_stride, z_scratch);
+    teacher_kt_tiled_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(z_scratch, n, n_s, gb, g_batch_stride, omega, tap0,
+                                                                     tap1, lam, range0, range1, kt, tnorm2);
     BASD_RETURN_LAST();
 }
 
