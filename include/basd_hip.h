@@ -233,6 +233,12 @@ int basd_student_project(const void* x, int dtype, long sb, long sn, int B, int 
 int basd_teacher_center(const void* const* tok_ptrs, int dtype, const float* mix, int L, long sb, long sn, long sd,
                         int B, int n, int D, const int* g0, const int* g1, const float* glam, const float* omega_t,
                         float* mu, float* tc, hipStream_t stream);
+/* The same for G <= 4 groups of mixing weights (mix: (G, L); multi-layer teachers: one group per extraction layer) in
+ * ONE pass over the teacher layers: omega_t (G, B, n), mu (G, B, D), tc (G, B, n, D).  Returns BASD_EUNSUPPORTED for
+ * more groups or tiles past LDS: call basd_teacher_center per group. */
+int basd_teacher_center_multi(const void* const* tok_ptrs, int dtype, const float* mix, int L, int G, long sb, long sn,
+                              long sd, int B, int n, int D, const int* g0, const int* g1, const float* glam,
+                              const float* omega_t, float* mu, float* tc, hipStream_t stream);
 
 /* G[b] = P[b] P[b]^T accumulated in fp64 on v_mfma_f64_16x16x4_f64 (the bmm of relational.py:47,
  * reduced to the teacher grid). */

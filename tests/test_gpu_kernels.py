@@ -515,3 +515,38 @@ def test_student_grad_fused_forms_h_in_the_kernel(dev, side_s, side_t, d_s, E, B
                   lm, grad_layers.data_ptr(), 2.0 / B, dx2.data_ptr(), None, None, ops._stream())
     torch.cuda.synchronize()
     assert _rel(torch.stack(grads), dx2) < 1e-5
+
+
+@pytest.mark.parametrize("n_t, n, D, L, G, layout, dtype", [
+    (196, 196, 100, 5, 4, "row", torch.float32),        # ViT teacher: CLS-sliced rows, last slab partly outside D
+    (49, 49, 64, 3, 2, "channel", torch.float32),       # channel-major (CNN feature maps)
+    (256, 64, 48, 4, 3, "row", torch.bfloat16),         # finer teacher grid gathered to 64 tokens, bf16
+])
+def test_teacher_center_multi_matches_per_group(dev, n_t, n, D, L, G, layout, dtype):
+    """basd_teacher_center_multi (all groups of mixing weights in one pass over the teacher layers) against
+    basd_teacher_center called once per group: same mixed, centred tokens and weighted means
+    (layer_selector.py:110-111 + relational.py:37,39)."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(n_t + D)
+    B = 3
+    if layout == "row":
+        full = [torch.randn(B, n_t + 1, D, generator=g).to(dev).to(dtype) for _ in range(L)]
+        toks = [f[:, 1:, :] for f in full]
+    else:
+        full = [torch.randn(B, D, n_t, generator=g).to(dev).to(dtype) for _ in range(L)]
+        toks = [f.transpose(1, 2) for f in full]
+    mix = torch.softmax(torch.randn(G, L, generator=g), dim=-1).to(dev)
+    omega_t = torch.softmax(torch.randn(G, B, n, generator=g), dim=-1).to(dev)
+    gt = ops.taps(n_t, n, dev) if n_t != n else None
+    g0, g1, gl = (gt.tap0.data_ptr(), gt.tap1.data_ptr(), gt.lam.data_ptr()) if gt else (None, None, None)
+    tab = ops._ptr_table(toks)
+    sb, sn, sd = toks[0].stride()
+    mu1, tc1 = torch.empty(G, B, D, device=dev), torch.empty(G, B, n, D, device=dev)
+    mu2, tc2 = torch.empty_like(mu1), torch.empty_like(tc1)
+    for k in range(G):
+        ops._lib.call("basd_teacher_center", tab.data_ptr(), ops._dtype_code(toks[0]), mix[k].data_ptr(), L, sb, sn, sd,
+                      B, n, D, g0, g1, gl, omega_t[k].data_ptr(), mu1[k].data_ptr(), tc1[k].data_ptr(), ops._stream())
+    ops._lib.call("basd_teacher_center_multi", tab.data_ptr(), ops._dtype_code(toks[0]), mix.data_ptr(), L, G, sb, sn,
+                  sd, B, n, D, g0, g1, gl, omega_t.data_ptr(), mu2.data_ptr(), tc2.data_ptr(), ops._stream())
+    torch.cuda.synchronize()
+    assert _rel(mu2, mu1) < 1e-5 and _rel(tc2, tc1) < 1e-5, (_rel(mu2, mu1), _rel(tc2, tc1))

@@ -52,6 +52,7 @@ SIGNATURES = {
                            vp, vp, vp, vp, vp, vp],
     "basd_student_project": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "basd_teacher_center": [vp, i32, vp, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "basd_teacher_center_multi": [vp, i32, vp, i32, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_gram_f64": [vp, i64, i32, i32, i32, vp, i64, vp],
     "basd_gram_f64_split": [vp, i64, i32, i32, i32, i32, vp, vp, vp],
     "basd_chol_f64": [vp, i64, i32, i32, vp, i64, vp],

@@ -714,11 +714,10 @@ def procrustes_teacher_factor(ctx: ProcrustesContext) -> tuple[torch.Tensor, tor
     common = (mg["W"].data_ptr(), 2 * n * n, mg["sigma"].data_ptr(), n, n_s, E * B, mg["l_a"].data_ptr(),
               mg["g_b"].data_ptr(), n * n, mg["omega_e"].data_ptr(), t0, t1, lam, r0, r1, kt.data_ptr(),
               tnorm2.data_ptr())
-    if 4 * (n + n * n) <= 156 * 1024:
-        _lib.call("basd_teacher_factor", *common, _stream())
-    else:                                             # cores past LDS: tiled, Z through scratch
-        scratch = torch.empty((E * B, n, n), device=dev, dtype=torch.float32)
-        _lib.call("basd_teacher_factor_tiled", *common, scratch.data_ptr(), _stream())
+    # the tiled form (Z through scratch) for every order: 0.87 ms against 7.5 for the LDS-resident kernel at 512 cores of
+    # 196 tokens, 0.04 against 0.19 at 64 tokens (tools/probe/teacher_factor_ab.py)
+    scratch = torch.empty((E * B, n, n), device=dev, dtype=torch.float32)
+    _lib.call("basd_teacher_factor_tiled", *common, scratch.data_ptr(), _stream())
     return kt, tnorm2
 
 

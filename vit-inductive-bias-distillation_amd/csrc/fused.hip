@@ -84,11 +84,20 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
         if (rc != BASD_OK) return rc; \
     } while (0)
     // teacher side: token weights + mixed, centred teacher, once per group (G = 1: shared by all layers)
+    int centred = BASD_EUNSUPPORTED;
     for (int g = 0; g < G; ++g) {
         BASD_TRY(basd_token_weights(a->attn_ptrs, (int)a->a_dtype, a->mix + (long)g * L, L, a->a_sb, a->a_sh, a->a_sq,
                                     a->a_sk, B, H, A, (int)a->has_cls, n_a, n, n_s, a->atap0, a->atap1, a->alam,
                                     a->tap0, a->tap1, a->lam, a->omega + (long)g * B * n_s,
                                     a->omega_t + (long)g * B * n, a->raw ? a->raw + (long)g * B * n_a : nullptr, st));
+    }
+    // mixed, centred teacher: all groups in one pass over the teacher layers where that applies
+    if (G > 1) {
+        centred = basd_teacher_center_multi(a->tok_ptrs, (int)a->t_dtype, a->mix, L, G, a->t_sb, a->t_sn, a->t_sd, B, n,
+                                            d_t, a->g0, a->g1, a->glam, a->omega_t, a->mu_t, a->tc, st);
+        if (centred != BASD_OK && centred != BASD_EUNSUPPORTED) return centred;
+    }
+    for (int g = 0; g < G && centred != BASD_OK; ++g) {
         BASD_TRY(basd_teacher_center(a->tok_ptrs, (int)a->t_dtype, a->mix + (long)g * L, L, a->t_sb, a->t_sn, a->t_sd,
                                      B, n, d_t, a->g0, a->g1, a->glam, a->omega_t + (long)g * B * n,
                                      a->mu_t + (long)g * B * d_t, a->tc + (long)g * B * n * d_t, st));

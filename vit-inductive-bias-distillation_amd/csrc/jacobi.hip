@@ -269,7 +269,8 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
 // columns is staged in LDS; what a sweep costs is the trips of the matrix through L2 / HBM -- nblk - 1 rounds, each
 // reading and writing every column once -- so the host picks the widest panel that fits (few lanes per pair when the
 // columns are short: 288 rows x 112 columns at cfg-5 is 3 rounds per sweep where one wave per pair and 32 columns
-// took 9).  Columns are padded to LPP * EPL rows.  flags[m * max_sweeps + s] != 0 <=> a rotation was applied in sweep s.
+// took 9).  Columns are padded to LPP * EPL rows.  flags[m * max_sweeps + s] != 0 <=> sweep s applied a rotation above
+// sqrt(tol), i.e. another sweep follows.
 // ---------------------------------------------------------------------------
 template <int EPL, int DOT, int LPP>
 __global__ void __launch_bounds__(1024) jacobi_block_round_kernel(float* __restrict__ W, long batch_stride,
@@ -357,7 +358,9 @@ __global__ void __launch_bounds__(1024) jacobi_block_round_kernel(float* __restr
         __syncthreads();
     }
     if (gl == 0 && norm2_max > 0.f) atomicMax(&norm2_bits[m * max_sweeps + sweep], __float_as_int(norm2_max));
-    if (__syncthreads_or(rotated) && tid == 0) atomicOr(&flags[m * max_sweeps + sweep], 1);
+    // the stopping rule of jacobi_lds_kernel: a sweep whose rotations all stayed below sqrt(tol) leaves O(tol) behind
+    // (quadratic convergence) and is the last one -- no extra sweep that would only verify it
+    if (__syncthreads_or(rotated & 2) && tid == 0) atomicOr(&flags[m * max_sweeps + sweep], 1);
 
     if (vec4) {
         const int q4 = rows_tot >> 2, total4 = 2 * BW * q4;
@@ -388,6 +391,15 @@ __global__ void __launch_bounds__(1024) jacobi_block_round_kernel(float* __restr
             }
         }
     }
+}
+
+// sweeps the block solver ran on matrix m: those that asked for another one, plus the last
+__global__ void block_sweeps_kernel(const int* __restrict__ flags, int batch, int max_sweeps, int* __restrict__ sweeps_out) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= batch) return;
+    int s = 0;
+    while (s < max_sweeps && flags[m * max_sweeps + s] != 0) ++s;
+    sweeps_out[m] = s < max_sweeps ? s + 1 : max_sweeps;
 }
 
 // column norms of a column-major batch (after the block solver). grid = (ceil(n/4), batch), block 256
@@ -688,6 +700,7 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
 #undef LAUNCH_BLOCK_SEL
 #undef LAUNCH_BLOCK
     if (!launched) return BASD_EUNSUPPORTED;
+    if (sweeps_out) block_sweeps_kernel<<<(batch + 255) / 256, 256, 0, stream>>>(flags, batch, max_sweeps, sweeps_out);
     colnorm_kernel<<<dim3((n + 3) / 4, batch), 256, 0, stream>>>(W, batch_stride, rows_dot, rows_tot, n, colnorm,
                                                                  colnorm_stride);
     BASD_RETURN_LAST();

@@ -420,6 +420,75 @@ __global__ void __launch_bounds__(256) teacher_center_kernel(const void* const* 
     }
 }
 
+// The same for G <= 4 groups of mixing weights in ONE pass over the teacher layers (multi-layer teachers: one group per
+// extraction layer; the per-group kernel read all L layers once per group -- 4 x 2.5 GB per step at cfg-4).  Slabs of 16
+// features so that the G tiles fit LDS together.  omega_t (G, B, n), mu_out (G, B, D), Tc (G, B, n, D).
+constexpr int TCM_W = 16, TCM_G = 4;
+template <typename T>
+__global__ void __launch_bounds__(256) teacher_center_multi_kernel(
+    const void* const* __restrict__ tok_ptrs, const float* __restrict__ mix, int L, int G, long sb, long sn, long sd,
+    int n, int D, const int* __restrict__ g0, const int* __restrict__ g1, const float* __restrict__ glam,
+    const float* __restrict__ omega_t, float* __restrict__ mu_out, float* __restrict__ Tc) {
+    extern __shared__ float sm[];
+    const int B = gridDim.y, b = blockIdx.y, d0 = blockIdx.x * TCM_W, tid = threadIdx.x;
+    float* tile = sm;                                      // G x n x (TCM_W + 1)
+    float* wt = sm + (size_t)G * n * (TCM_W + 1);          // G x n
+    float* mu = wt + (size_t)G * n;                        // G x TCM_W
+    for (int idx = tid; idx < G * n; idx += 256) {
+        const int g = idx / n, j = idx - g * n;
+        wt[idx] = omega_t[((long)g * B + b) * n + j];
+    }
+    const int total = n * TCM_W;
+    const bool feat_fast = sd == 1;
+    for (int idx = tid; idx < total; idx += 256) {
+        int j, dd;
+        if (feat_fast) { j = idx / TCM_W; dd = idx - j * TCM_W; }
+        else { dd = idx / n; j = idx - dd * n; }
+        const int d = d0 + dd;
+        float v[TCM_G] = {0.f, 0.f, 0.f, 0.f};
+        if (d < D) {
+            const long off = b * sb + (long)d * sd;
+            if (g0) {
+                const long r0 = g0[j], r1 = g1[j];
+                const float l1 = glam[j], l0 = 1.f - l1;
+                for (int l = 0; l < L; ++l) {
+                    const BASD_GLOBAL_AS T* p = (const BASD_GLOBAL_AS T*)tok_ptrs[l];
+                    const float x = l0 * ldg_f32(p + (off + r0 * sn)) + l1 * ldg_f32(p + (off + r1 * sn));
+#pragma unroll
+                    for (int g = 0; g < TCM_G; ++g)
+                        if (g < G) v[g] = fmaf(mix[g * L + l], x, v[g]);
+                }
+            } else {
+                for (int l = 0; l < L; ++l) {
+                    const float x = ldg_f32((const BASD_GLOBAL_AS T*)tok_ptrs[l] + (off + (long)j * sn));
+#pragma unroll
+                    for (int g = 0; g < TCM_G; ++g)
+                        if (g < G) v[g] = fmaf(mix[g * L + l], x, v[g]);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < TCM_G; ++g)
+            if (g < G) tile[((size_t)g * n + j) * (TCM_W + 1) + dd] = v[g];
+    }
+    __syncthreads();
+    if (tid < TCM_W * G) {
+        const int g = tid / TCM_W, dd = tid - g * TCM_W;
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc = fmaf(wt[g * n + j], tile[((size_t)g * n + j) * (TCM_W + 1) + dd], acc);
+        mu[tid] = acc;
+        if (d0 + dd < D) mu_out[((long)g * B + b) * D + d0 + dd] = acc;
+    }
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+        float* out = Tc + ((long)g * B + b) * n * D;
+        for (int idx = tid; idx < total; idx += 256) {
+            const int j = idx / TCM_W, dd = idx - j * TCM_W, d = d0 + dd;
+            if (d < D) out[(long)j * D + d] = tile[((size_t)g * n + j) * (TCM_W + 1) + dd] - mu[g * TCM_W + dd];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Batched Gram in fp64 on the f64 MFMA: G[b] = P[b] P[b]^T, P: (n x D) fp32 row-major.
 // grid = batch, block = 64 * waves.  Lower tiles (16 x 16) are dealt round-robin to waves.
@@ -693,22 +762,45 @@ __global__ void __launch_bounds__(1024) chol_f64_blocked_kernel(const double* __
 // ---------------------------------------------------------------------------
 // W[b] = [ L_a^T L_b ; L_b ]   (2n x n, column-major fp32, leading dimension 2n), fp64 accumulate.
 // stack_product_kernel: grid = batch, block = 256, both factors in LDS (n <= 98).
-// stack_product_global_kernel: grid = (ceil(n*n/256), batch), factors read from L2 (larger n).
+// stack_product_global_kernel: grid = (ceil(n/32), ceil(n/32), batch), tiles of the factors through LDS (larger n).
 // ---------------------------------------------------------------------------
+// 32 x 32 output tiles, both factors staged through LDS in fp64; the zeros stored above the diagonals make
+// k >= 32 max(tile_i, tile_j) the exact start of the sum.  (The first version read the factors element-wise from L2 inside
+// the k loop: 5.4 ms per step at cfg-4, 17 ms for 64 cores of 576 tokens.)
 __global__ void __launch_bounds__(256) stack_product_global_kernel(const double* __restrict__ La,
                                                                    const double* __restrict__ Lb,
                                                                    long l_batch_stride, int n, float* __restrict__ W,
                                                                    long w_batch_stride, int lb_period) {
-    const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * n) return;
-    const int i = idx / n, j = idx - i * n;   // consecutive threads: consecutive j
+    __shared__ double ta[32][33], tb[32][33];     // [k][i], [k][j]
+    const int b = blockIdx.z, i0 = blockIdx.x * 32, j0 = blockIdx.y * 32, tid = threadIdx.x;
     const double* A = La + (long)b * l_batch_stride;
     const double* B = Lb + (long)(b % lb_period) * l_batch_stride;
-    double acc = 0.;
-    for (int k = (i > j ? i : j); k < n; ++k) acc = fma(A[(long)k * n + i], B[(long)k * n + j], acc);
+    const int tx = tid & 31, ty = tid >> 5;       // tx: i within the tile, ty + 8 r: j within the tile
+    double acc[4] = {0., 0., 0., 0.};
+    for (int k0 = i0 > j0 ? i0 : j0; k0 < n; k0 += 32) {
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int kk = idx >> 5, c = idx & 31, k = k0 + kk;
+            ta[kk][c] = (k < n && i0 + c < n) ? A[(long)k * n + i0 + c] : 0.;
+            tb[kk][c] = (k < n && j0 + c < n) ? B[(long)k * n + j0 + c] : 0.;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const double av = ta[kk][tx];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fma(av, tb[kk][ty + 8 * r], acc[r]);
+        }
+    }
     float* Wb = W + (long)b * w_batch_stride;
-    Wb[(long)j * 2 * n + i] = (float)acc;
-    Wb[(long)j * 2 * n + n + i] = (float)B[(long)i * n + j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + tx, j = j0 + ty + 8 * r;
+        if (i < n && j < n) {
+            Wb[(long)j * 2 * n + i] = (float)acc[r];
+            Wb[(long)j * 2 * n + n + i] = (float)B[(long)i * n + j];
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) stack_product_kernel(const double* __restrict__ La,
@@ -1113,6 +1205,30 @@ int basd_teacher_center(const void* const* tok_ptrs, int dtype, const float* mix
     BASD_RETURN_LAST();
 }
 
+// basd_teacher_center for G <= 4 groups of mixing weights (mix: (G, L)) in one pass over the teacher layers.
+// omega_t (G, B, n), mu (G, B, D), tc (G, B, n, D).  BASD_EUNSUPPORTED: more groups, or tiles past LDS -- call the
+// per-group entry.
+int basd_teacher_center_multi(const void* const* tok_ptrs, int dtype, const float* mix, int L, int G, long sb, long sn,
+                              long sd, int B, int n, int D, const int* g0, const int* g1, const float* glam,
+                              const float* omega_t, float* mu, float* tc, hipStream_t stream) {
+    BASD_CHECK_ARG(tok_ptrs && mix && omega_t && mu && tc && L > 0 && G > 0 && B > 0 && n > 0 && D > 0);
+    BASD_CHECK_ARG((g0 == nullptr) == (g1 == nullptr) && (g0 == nullptr) == (glam == nullptr));
+    BASD_CHECK_ARG(B <= 65535);
+    const size_t lds = sizeof(float) * ((size_t)G * n * (TCM_W + 1) + (size_t)G * n + (size_t)G * TCM_W);
+    if (G > TCM_G || lds > 150 * 1024) return BASD_EUNSUPPORTED;
+    const dim3 grid((D + TCM_W - 1) / TCM_W, B);
+    if (dtype == BASD_DTYPE_F32) {
+        (void)hipFuncSetAttribute((const void*)teacher_center_multi_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        teacher_center_multi_kernel<float><<<grid, 256, lds, stream>>>(tok_ptrs, mix, L, G, sb, sn, sd, n, D, g0, g1, glam, omega_t, mu, tc);
+    } else if (dtype == BASD_DTYPE_BF16) {
+        (void)hipFuncSetAttribute((const void*)teacher_center_multi_kernel<__hip_bfloat16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        teacher_center_multi_kernel<__hip_bfloat16><<<grid, 256, lds, stream>>>(tok_ptrs, mix, L, G, sb, sn, sd, n, D, g0, g1, glam, omega_t, mu, tc);
+    } else {
+        return BASD_EINVAL;
+    }
+    BASD_RETURN_LAST();
+}
+
 // G[b] = P[b] P[b]^T in fp64 (the bmm of relational.py:47 reduced to the teacher grid).
 int basd_gram_f64(const float* p, long p_batch_stride, int n, int D, int batch, double* g, long g_batch_stride,
                   hipStream_t stream) {
@@ -1167,7 +1283,9 @@ int basd_stack_product(const double* la, const double* lb, long l_batch_stride, 
         (void)hipFuncSetAttribute((const void*)stack_product_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024);
         stack_product_kernel<<<batch, 256, lds, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride, lb_period);
     } else {
-        stack_product_global_kernel<<<dim3((n * n + 255) / 256, batch), 256, 0, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride, lb_period);
+        BASD_CHECK_ARG(batch <= 65535);
+        const int nt = (n + 31) / 32;
+        stack_product_global_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride, lb_period);
     }
     BASD_RETURN_LAST();
 }
