@@ -111,6 +111,16 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
                          const int* n_arr, float* colnorm, int colnorm_stride, int max_sweeps, float tol_cos,
                          int* flags, int* sweeps_out, hipStream_t stream);
 
+/* The same for stacked square cores [M; L_b] (2n x n, leading dimension 2n; the Procrustes cores of relational.py:48)
+ * whose 2n rows do not fit LDS while n rows do (n = 129..196: cfg-5's 144, cfg-4's 196): pass 1 solves the top n x n
+ * in LDS and logs every rotation, pass 2 replays the log on the riding rows in LDS -- the same rotations in the same
+ * order as the one-kernel solver, without the block solver's trips through L2 / HBM.  workspace: device memory of
+ * basd_jacobi_twopass_workspace_bytes() bytes, 8-byte aligned (0 bytes = shape not covered: BASD_EUNSUPPORTED, use
+ * basd_jacobi_onesided). */
+long basd_jacobi_twopass_workspace_bytes(int n, int batch, int max_sweeps);
+int basd_jacobi_stacked_twopass(float* W, long batch_stride, int n, int batch, float* colnorm, int colnorm_stride,
+                                int max_sweeps, float tol_cos, void* workspace, int* sweeps_out, hipStream_t stream);
+
 /* Sort column norms descending; optionally emit the top-kmax normalised columns as rows
  * (`Vt[:k]` of layer_selector.py:37, :97). */
 int basd_sort_extract(const float* W, long batch_stride, int rows, int rows_tot, int n, int batch,
@@ -334,6 +344,9 @@ typedef struct BasdProcrustesArgs {
      * uw_out (4 + 2 E floats) receives w_ce, w_geo, total, geo, then E x w_geo / E, then the E per-layer means.  The
      * student gradients (dx) are then those of `total` for a unit upstream gradient and grad_layers is ignored. */
     const float* uw_ce; float* uw_out;
+    /* nullable: basd_jacobi_twopass_workspace_bytes(n, E*B, max_sweeps) bytes; the SVD then takes
+     * basd_jacobi_stacked_twopass where that covers the shape */
+    void* jac_ws;
 } BasdProcrustesArgs;
 int basd_procrustes_forward_fused(const BasdProcrustesArgs* args, hipStream_t stream);
 

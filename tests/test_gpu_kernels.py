@@ -550,3 +550,59 @@ def test_teacher_center_multi_matches_per_group(dev, n_t, n, D, L, G, layout, dt
                   sd, B, n, D, g0, g1, gl, omega_t.data_ptr(), mu2.data_ptr(), tc2.data_ptr(), ops._stream())
     torch.cuda.synchronize()
     assert _rel(mu2, mu1) < 1e-5 and _rel(tc2, tc1) < 1e-5, (_rel(mu2, mu1), _rel(tc2, tc1))
+
+
+@pytest.mark.parametrize("n, batch", [(144, 3), (196, 2), (130, 2), (177, 2), (190, 2)])
+def test_jacobi_two_pass_invariants(dev, n, batch):
+    """basd_jacobi_stacked_twopass (top n x n solved in LDS with a rotation log, the log replayed on the riding rows):
+    singular values, orthogonality of the top half, and the right-orthogonal invariants that tie the riding rows to
+    the same rotations -- the checks of test_jacobi_lds_invariants."""
+    from basd_amd import ops, _lib
+    g = torch.Generator().manual_seed(n)
+    w0 = torch.randn(batch, n, 2 * n, generator=g)
+    w0[:, :, :n] *= torch.logspace(0, -3, n).view(1, n, 1)
+    W = w0.clone().to(dev)
+    nbytes = _lib.query("basd_jacobi_twopass_workspace_bytes", n, batch, ops.MAX_SWEEPS)
+    assert nbytes > 0
+    ws = torch.empty((nbytes // 8 + 1,), device=dev, dtype=torch.int64)
+    sigma = torch.empty((batch, n), device=dev)
+    sweeps = torch.zeros((batch,), device=dev, dtype=torch.int32)
+    _lib.call("basd_jacobi_stacked_twopass", W.data_ptr(), 2 * n * n, n, batch, sigma.data_ptr(), n, ops.MAX_SWEEPS, 0.0,
+              ws.data_ptr(), sweeps.data_ptr(), ops._stream())
+    torch.cuda.synchronize()
+    assert 0 < int(sweeps.max()) < ops.MAX_SWEEPS, "did not converge"
+    top0, bot0 = w0[:, :, :n].double(), w0[:, :, n:].double()
+    top, bot = W[:, :, :n].double().cpu(), W[:, :, n:].double().cpu()
+    sv = torch.linalg.svdvals(top0)
+    got = sigma.double().cpu().sort(dim=1, descending=True).values
+    assert ((got - sv).abs().max(dim=1).values / sv[:, 0]).max() < 3e-6
+    gram = top @ top.transpose(1, 2)
+    off = gram - torch.diag_embed(torch.diagonal(gram, dim1=1, dim2=2))
+    nrm = torch.diagonal(gram, dim1=1, dim2=2).sqrt()
+    live = (nrm > 1e-6 * nrm.amax(dim=1, keepdim=True)).double()
+    cos = off.abs() / (nrm.unsqueeze(2) * nrm.unsqueeze(1)).clamp_min(1e-30) * live.unsqueeze(2) * live.unsqueeze(1)
+    assert cos.max().item() < 5e-6, cos.max().item()
+    assert _rel(bot.transpose(1, 2) @ bot, bot0.transpose(1, 2) @ bot0) < 1e-5
+    assert _rel(top.transpose(1, 2) @ bot, top0.transpose(1, 2) @ bot0) < 1e-5
+    assert _lib.query("basd_jacobi_twopass_workspace_bytes", 49, 1024, ops.MAX_SWEEPS) == 0     # fits the one-kernel solver
+    assert _lib.query("basd_jacobi_twopass_workspace_bytes", 576, 4, ops.MAX_SWEEPS) == 0      # past LDS: block solver
+
+
+@pytest.mark.parametrize("n_s, n_t", [(576, 144), (196, 196)])
+def test_procrustes_two_pass_svd_matches_block_solver(dev, n_s, n_t, monkeypatch):
+    """The Procrustes forward with the two-pass SVD against the block solver on the same cores (cfg-5's 144 tokens,
+    cfg-4's 196): per-sample terms and K'."""
+    from basd_amd import ops, synth
+    g = torch.Generator().manual_seed(n_s + n_t)
+    B, d_s, d_t = 3, 256, 320
+    s = synth.structured(g, B, n_s, d_s, 16).to(dev)
+    t = synth.structured(g, B, n_t, d_t, 12).to(dev)
+    attn = torch.softmax(torch.randn(B, 2, n_t, n_t, generator=g), dim=-1).to(dev)
+    mix = torch.ones(1, 1, device=dev)
+    a = ops.procrustes_forward([s], [t], [attn], mix, False, want_sweeps=True)
+    monkeypatch.setattr(ops, "TWO_PASS_SVD", False)
+    b = ops.procrustes_forward([s], [t], [attn], mix, False, want_sweeps=True)
+    torch.cuda.synchronize()
+    assert int(a.sweeps.max()) < ops.MAX_SWEEPS
+    assert _rel(a.nuc, b.nuc) < 2e-6 and _rel(a.loss_b, b.loss_b) < 1e-5
+    assert _rel(a.k_prime, b.k_prime) < 2e-5, _rel(a.k_prime, b.k_prime)

@@ -27,6 +27,8 @@ SIGNATURES = {
     "basd_syrk_splits": [i32, i32, i32],
     "basd_syrk_multi": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, i32, vp, vp, i64, i32, vp, i32, i32, vp],
     "basd_jacobi_workspace_ints": [i32, i32],
+    "basd_jacobi_twopass_workspace_bytes": [i32, i32, i32],
+    "basd_jacobi_stacked_twopass": [vp, i64, i32, i32, vp, i32, i32, f32, vp, vp, vp],
     "basd_jacobi_tuning": [i32],
     "basd_jacobi_onesided": [vp, i64, i32, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp],
     "basd_sort_extract": [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
@@ -95,14 +97,14 @@ class ProcrustesArgs(C.Structure):
                              "l_all", "W", "sigma", "jflags", "sweeps", "tr_t", "nuc", "loss_b", "k_prime", "h", "dx",
                              "grad_layers", "g_slabs")]
         + [("g_splits", i64)]
-        + [("uw_ce", vp), ("uw_out", vp)]
+        + [("uw_ce", vp), ("uw_out", vp), ("jac_ws", vp)]
     )
 
 
 EINVAL, EUNSUPPORTED = -1, -2        # BASD_EINVAL / BASD_EUNSUPPORTED of include/basd_hip.h
 
 # sizing helpers declared `long` in include/basd_hip.h
-LONG_RESULTS = {"basd_tridiag_workspace_bytes"}
+LONG_RESULTS = {"basd_tridiag_workspace_bytes", "basd_jacobi_twopass_workspace_bytes"}
 
 _lock = threading.Lock()
 _lib = None

@@ -17,6 +17,7 @@ import os
 
 F32, BF16 = 0, 1
 MAX_SWEEPS = 20
+TWO_PASS_SVD = True      # test hook: False sends cores of 129..196 tokens through the block solver instead
 # Symmetric eigen-solver for the selector's D_s x D_s Grams when only eigenvalues / leading eigenvectors are
 # needed: "tridiag" (Householder + bisection + inverse iteration) or "jacobi" (block one-sided Jacobi).
 EIG_SOLVER = os.environ.get("BASD_EIG_SOLVER", "tridiag")
@@ -597,6 +598,9 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     if want_sweeps:
         sweeps = ints[-EB:]
         sweeps.zero_()
+    # cores whose 2n rows are past LDS while n rows fit: rotation log of the two-pass SVD (0 bytes: shape not covered)
+    jac_bytes = _lib.query("basd_jacobi_twopass_workspace_bytes", n, EB, MAX_SWEEPS) if TWO_PASS_SVD else 0
+    jac_ws = torch.empty((jac_bytes // 8 + 1,), device=dev, dtype=torch.int64) if jac_bytes > 0 else None
     raw = torch.empty((G, B, n_a), **f32) if need_mix_grad else None
     h = dx = uw = None
     if uwso_ce is not None:
@@ -638,6 +642,7 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     args.h, args.dx, args.grad_layers = _ptr(h), _ptr(dx), _ptr(grad_layers)
     args.g_slabs, args.g_splits = _ptr(g_slabs), g_splits
     args.uw_ce, args.uw_out = _ptr(uwso_ce), _ptr(uw)
+    args.jac_ws = _ptr(jac_ws)
     gpu_mark("procrustes_begin")
     _lib.call("basd_procrustes_forward_fused", ctypes.addressof(args), _stream())
     gpu_mark("procrustes_end")

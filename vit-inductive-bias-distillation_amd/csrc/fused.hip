@@ -129,8 +129,14 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
         BASD_TRY(basd_gram_f64(a->tc, (long)n * d_t, n, d_t, GB, a->g_all + (long)EB * nn, nn, st));
     BASD_TRY(basd_chol_f64(a->g_all, nn, n, EB + GB, a->l_all, nn, st));
     BASD_TRY(basd_stack_product(a->l_all, a->l_all + (long)EB * nn, nn, n, EB, GB, a->W, 2 * nn, st));
-    BASD_TRY(basd_jacobi_onesided(a->W, 2 * nn, n, 2 * n, n, EB, nullptr, a->sigma, n, (int)a->max_sweeps, 0.f,
-                                  a->jflags, a->sweeps, st));
+    rc = BASD_EUNSUPPORTED;
+    if (a->jac_ws)
+        rc = basd_jacobi_stacked_twopass(a->W, 2 * nn, n, EB, a->sigma, n, (int)a->max_sweeps, 0.f, a->jac_ws, a->sweeps,
+                                         st);
+    if (rc == BASD_EUNSUPPORTED)
+        rc = basd_jacobi_onesided(a->W, 2 * nn, n, 2 * n, n, EB, nullptr, a->sigma, n, (int)a->max_sweeps, 0.f,
+                                  a->jflags, a->sweeps, st);
+    if (rc != BASD_OK) return rc;
     BASD_TRY(basd_procrustes_finalize(a->W, 2 * nn, a->sigma, n, n_s, EB, GB, a->g_all + (long)EB * nn, nn, a->omega,
                                       a->tap0, a->tap1, a->lam, a->tr_part, slabs, a->tr_s, a->tr_t, a->nuc,
                                       a->loss_b, a->k_prime, st));

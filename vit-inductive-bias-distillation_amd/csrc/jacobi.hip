@@ -98,11 +98,11 @@ __device__ __forceinline__ float pair_allsum(float x) {
 // would keep the sweep loop alive for ever, so pairs involving them count as converged.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int EPL, int DOT, int LPP>
+template <int EPL, int DOT, int LPP, bool LOG = false>
 __device__ __forceinline__ int rotate_pair(float* __restrict__ cp, float* __restrict__ cq, int gl, float tol,
                                             float null2, float& norm2_max, float* __restrict__ n2p,
                                             float* __restrict__ n2q, float* __restrict__ devp,
-                                            float* __restrict__ devq) {
+                                            float* __restrict__ devq, f32x2* __restrict__ logp = nullptr) {
     // lane gl owns the row pairs (2 gl, 2 gl + 1) + 2 LPP i: 8-byte LDS accesses and packed fp32 math
     static_assert(EPL % 2 == 0 && DOT % 2 == 0, "row chunks come in pairs");
     constexpr int H = EPL / 2, HD = DOT / 2;
@@ -120,9 +120,16 @@ __device__ __forceinline__ int rotate_pair(float* __restrict__ cp, float* __rest
     const float g = pair_allsum<LPP>(acc.x + acc.y);
     const float a = *n2p, b = *n2q;
     norm2_max = fmaxf(norm2_max, fmaxf(a, b));
-    if (fminf(a, b) <= null2) return 0;
+    // LOG: (c, s) of every pair-step goes to a log that jacobi_apply_log_kernel replays on the riding rows
+    if (fminf(a, b) <= null2) {
+        if (LOG && gl == 0) *logp = f32x2{1.f, 0.f};
+        return 0;
+    }
     const Rot rot = make_rotation(a, b, g, tol);   // identical in every lane of the group
-    if (!rot.apply) return 0;
+    if (!rot.apply) {
+        if (LOG && gl == 0) *logp = f32x2{1.f, 0.f};
+        return 0;
+    }
     const f32x2 c2 = {rot.c, rot.c}, s2 = {rot.s, rot.s};
 #pragma unroll
     for (int i = 0; i < HD; ++i) {
@@ -141,6 +148,7 @@ __device__ __forceinline__ int rotate_pair(float* __restrict__ cp, float* __rest
         *n2q = b + rot.t * g;
         *devp += rot.h;
         *devq += rot.h;
+        if (LOG) *logp = f32x2{rot.c, rot.s};
     }
     return rot.strong ? 3 : 1;      // bit 0: rotated, bit 1: by more than sqrt(tol)
 }
@@ -260,6 +268,153 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
         const int c = idx / rt, r = idx - c * rt;
         const float v = lds[c * LD + lds_row<EPL, DOT, LPP>(r, rd)];
         Wm[(long)c * rows_tot + r] = fmaf(v, dev[c], v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Two-pass solver for stacked cores [M; L_b] (2n x n) whose 2n rows do not fit LDS while n rows do (n = 144 at cfg-5,
+// 196 at cfg-4: the block solver above moves the matrix through L2 / HBM n_blocks - 1 times per sweep).
+//   pass 1, jacobi_top_logged_kernel: the LDS-resident solver on the top n x n alone, every pair-step's (c, s) written
+//           to a log (8 bytes per pair-step; identity where no rotation was applied), plus the accumulated
+//           normalisation defects and the number of sweeps.
+//   pass 2, jacobi_apply_log_kernel: the riding rows in LDS, the log replayed on them -- no dot products, no
+//           reductions, the same rotations in the same order, so the result is what the one-kernel form computes.
+// 4 lanes per column pair; column stride LPP EPL (+ 8) = 8 x odd (see jacobi_lds_kernel).
+// Log entry of (sweep s, round r, pair seat t): ((s (n_even - 1) + r) n_even / 2 + t).
+// ---------------------------------------------------------------------------
+template <int EPL>
+struct TwoPassShape {
+    static constexpr int LPP = 4;
+    static constexpr int LD = LPP * EPL + (((LPP * EPL / 8) % 2 == 0) ? 8 : 0);
+    static_assert((LD / 8) % 2 == 1 && LD % 8 == 0, "stride must come out as 8 x odd");
+};
+
+template <int EPL>
+__global__ void __launch_bounds__(512) jacobi_top_logged_kernel(float* __restrict__ W, long batch_stride, int ld, int n,
+                                                                int max_sweeps, float tol, float* __restrict__ colnorm,
+                                                                int colnorm_stride, f32x2* __restrict__ rotlog,
+                                                                long log_stride, float* __restrict__ dev_out,
+                                                                int* __restrict__ sweeps_out) {
+    constexpr int LPP = TwoPassShape<EPL>::LPP, LD = TwoPassShape<EPL>::LD;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int m = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    float* Wm = W + (long)m * batch_stride;
+    f32x2* logm = rotlog + (long)m * log_stride;
+    const int n_even = (n + 1) & ~1;
+    for (int idx = tid; idx < n_even * LD; idx += nthr) lds[idx] = 0.f;
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += nthr) {
+        const int c = idx / n, r = idx - c * n;
+        lds[c * LD + r] = Wm[(long)c * ld + r];
+    }
+    __syncthreads();
+    const int groups = nthr / LPP, grp = tid / LPP, gl = tid % LPP;
+    float* n2 = lds + n_even * LD;
+    float* dev = n2 + n_even;
+    __shared__ int s_norm2_bits;
+    if (tid == 0) s_norm2_bits = 0;
+    for (int c = tid; c < n_even; c += nthr) dev[c] = 0.f;
+    float null2 = 0.f;
+    int sweep = 0;
+    const int pairs = n_even / 2;
+    for (; sweep < max_sweeps && n > 1; ++sweep) {
+        int rotated = 0;
+        float norm2_max = 0.f;
+        for (int c = grp; c < n_even; c += groups) {
+            const float v = column_norm2<EPL, LPP>(lds + c * LD, gl);
+            if (gl == 0) n2[c] = v;
+        }
+        __syncthreads();
+        for (int r = 0; r < n_even - 1; ++r) {
+            f32x2* logr = logm + ((long)sweep * (n_even - 1) + r) * pairs;
+            for (int t = grp; t < pairs; t += groups) {
+                int p, q;
+                rr_pair(n_even, r, t, p, q);
+                if (p >= n || q >= n) {
+                    if (gl == 0) logr[t] = f32x2{1.f, 0.f};
+                    continue;
+                }
+                if (p > q) { const int tmp = p; p = q; q = tmp; }
+                rotated |= rotate_pair<EPL, EPL, LPP, true>(lds + p * LD, lds + q * LD, gl, tol, null2, norm2_max, n2 + p,
+                                                            n2 + q, dev + p, dev + q, logr + t);
+            }
+            __syncthreads();
+        }
+        if (gl == 0 && norm2_max > 0.f) atomicMax(&s_norm2_bits, __float_as_int(norm2_max));
+        if (!__syncthreads_or(rotated & 2)) {
+            ++sweep;
+            break;
+        }
+        null2 = kNull2 * __int_as_float(s_norm2_bits);
+    }
+    if (tid == 0) sweeps_out[m] = sweep;
+    for (int c = grp; c < n; c += groups) {
+        const float a = column_norm2<EPL, LPP>(lds + c * LD, gl);
+        if (gl == 0) {
+            const float nv = sqrtf(a);
+            colnorm[(long)m * colnorm_stride + c] = fmaf(nv, dev[c], nv);
+            dev_out[(long)m * n + c] = dev[c];
+        }
+    }
+    for (int idx = tid; idx < n * n; idx += nthr) {
+        const int c = idx / n, r = idx - c * n;
+        const float v = lds[c * LD + r];
+        Wm[(long)c * ld + r] = fmaf(v, dev[c], v);
+    }
+}
+
+template <int EPL>
+__global__ void __launch_bounds__(512) jacobi_apply_log_kernel(float* __restrict__ W, long batch_stride, int ld, int row0,
+                                                               int n, const f32x2* __restrict__ rotlog, long log_stride,
+                                                               const float* __restrict__ dev_in,
+                                                               const int* __restrict__ sweeps) {
+    constexpr int LPP = TwoPassShape<EPL>::LPP, LD = TwoPassShape<EPL>::LD, H = EPL / 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int m = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    float* Wm = W + (long)m * batch_stride + row0;
+    const f32x2* logm = rotlog + (long)m * log_stride;
+    const int n_even = (n + 1) & ~1, pairs = n_even / 2;
+    for (int idx = tid; idx < n_even * LD; idx += nthr) lds[idx] = 0.f;
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += nthr) {
+        const int c = idx / n, r = idx - c * n;
+        lds[c * LD + r] = Wm[(long)c * ld + r];
+    }
+    __syncthreads();
+    const int grp = tid / LPP, gl = tid % LPP;          // one pair seat per lane group: nthr >= LPP * pairs
+    const long steps = (long)sweeps[m] * (n_even - 1);
+    const bool seat = grp < pairs;
+    const f32x2 ident = {1.f, 0.f};
+    // the (c, s) of this seat, two rounds ahead of their use (the log comes from L2 / HBM)
+    f32x2 cs0 = seat && steps > 0 ? logm[grp] : ident;
+    f32x2 cs1 = seat && steps > 1 ? logm[pairs + grp] : ident;
+    for (long st = 0; st < steps; ++st) {
+        const f32x2 cs2 = seat && st + 2 < steps ? logm[(st + 2) * pairs + grp] : ident;
+        const int r = (int)(st % (n_even - 1));
+        if (seat && (cs0.y != 0.f || cs0.x != 1.f)) {
+            int p, q;
+            rr_pair(n_even, r, grp, p, q);
+            if (p > q) { const int tmp = p; p = q; q = tmp; }
+            float* cp = lds + p * LD;
+            float* cq = lds + q * LD;
+            const f32x2 c2 = {cs0.x, cs0.x}, s2 = {cs0.y, cs0.y};
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const f32x2 xr = *(const f32x2*)(cp + 2 * gl + 2 * LPP * i);
+                const f32x2 yr = *(const f32x2*)(cq + 2 * gl + 2 * LPP * i);
+                *(f32x2*)(cp + 2 * gl + 2 * LPP * i) = __builtin_elementwise_fma(c2, xr, -(s2 * yr));
+                *(f32x2*)(cq + 2 * gl + 2 * LPP * i) = __builtin_elementwise_fma(s2, xr, c2 * yr);
+            }
+        }
+        __syncthreads();
+        cs0 = cs1;
+        cs1 = cs2;
+    }
+    const float* dv = dev_in + (long)m * n;
+    for (int idx = tid; idx < n * n; idx += nthr) {
+        const int c = idx / n, r = idx - c * n;
+        const float v = lds[c * LD + r];
+        Wm[(long)c * ld + r] = fmaf(v, dv[c], v);
     }
 }
 
@@ -703,6 +858,74 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
     if (sweeps_out) block_sweeps_kernel<<<(batch + 255) / 256, 256, 0, stream>>>(flags, batch, max_sweeps, sweeps_out);
     colnorm_kernel<<<dim3((n + 3) / 4, batch), 256, 0, stream>>>(W, batch_stride, rows_dot, rows_tot, n, colnorm,
                                                                  colnorm_stride);
+    BASD_RETURN_LAST();
+}
+
+// Two-pass solver (see jacobi_top_logged_kernel) for stacked square cores [M; L_b] (2n x n, leading dimension 2n).
+// Lane-element counts instantiated: n <= 4 EPL.
+static int twopass_epl(int n) {
+    static const int epls[] = {28, 36, 44, 50};
+    const size_t n_even = (n + 1) & ~1;
+    for (int e : epls)
+        if (n <= 4 * e) {
+            const size_t ld = 4 * e + (((4 * e / 8) % 2 == 0) ? 8 : 0);          // TwoPassShape<e>::LD
+            return sizeof(float) * (n_even * ld + 2 * n_even) <= BASD_JACOBI_LDS_LIMIT ? e : 0;   // n <= 196
+        }
+    return 0;
+}
+static bool stacked_lds_fits(int n) {              // the one-kernel LDS solver of basd_jacobi_onesided for a 2n x n core
+    const int n_even = (n + 1) & ~1, epl = 2 * ((n + 15) / 16);
+    static const int lds_epl[] = {4, 8, 12, 16, 20};
+    for (int e : lds_epl)
+        if (e >= epl) return (size_t)n_even * (16 * e + 4) * sizeof(float) <= BASD_JACOBI_LDS_LIMIT;
+    return false;
+}
+// Bytes of device workspace basd_jacobi_stacked_twopass needs (rotation log + defects + sweep counts); 0 when the
+// shape is not one it covers (cores that fit the one-kernel LDS solver: n <= 128, or n > 196).
+long basd_jacobi_twopass_workspace_bytes(int n, int batch, int max_sweeps) {
+    if (n < 2 || batch <= 0 || max_sweeps <= 0 || stacked_lds_fits(n) || !twopass_epl(n)) return 0;
+    const long n_even = (n + 1) & ~1;
+    const long entries = (long)max_sweeps * (n_even - 1) * (n_even / 2);
+    return (long)batch * (entries * 8 + (long)n * 4 + 4) + 64;
+}
+int basd_jacobi_stacked_twopass(float* W, long batch_stride, int n, int batch, float* colnorm, int colnorm_stride,
+                                int max_sweeps, float tol_cos, void* workspace, int* sweeps_out, hipStream_t stream) {
+    BASD_CHECK_ARG(W && colnorm && workspace && n > 1 && batch > 0 && max_sweeps > 0);
+    BASD_CHECK_ARG(((uintptr_t)workspace & 7) == 0);
+    const int epl = twopass_epl(n);
+    if (!epl || stacked_lds_fits(n)) return BASD_EUNSUPPORTED;
+    const float tol = tol_cos > 0.f ? tol_cos : 1.2e-7f * sqrtf((float)n);
+    const long n_even = (n + 1) & ~1;
+    const long entries = (long)max_sweeps * (n_even - 1) * (n_even / 2);
+    f32x2* rotlog = (f32x2*)workspace;
+    float* dev = (float*)(rotlog + (long)batch * entries);
+    int* sweeps = (int*)(dev + (long)batch * n);
+    int threads = (int)(((n_even / 2) * 4 + 63) / 64) * 64;
+    BASD_CHECK_ARG(threads <= 512);
+#define LAUNCH_2P(E)                                                                                                  \
+    do {                                                                                                              \
+        const size_t lds = sizeof(float) * ((size_t)n_even * TwoPassShape<E>::LD + 2 * (size_t)n_even);               \
+        if (lds > BASD_JACOBI_LDS_LIMIT) return BASD_EUNSUPPORTED;                                                    \
+        (void)hipFuncSetAttribute((const void*)jacobi_top_logged_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  BASD_JACOBI_LDS_LIMIT);                                                             \
+        (void)hipFuncSetAttribute((const void*)jacobi_apply_log_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  BASD_JACOBI_LDS_LIMIT);                                                             \
+        jacobi_top_logged_kernel<E><<<batch, threads, lds, stream>>>(W, batch_stride, 2 * n, n, max_sweeps, tol, colnorm, \
+                                                                     colnorm_stride, rotlog, entries, dev, sweeps);   \
+        jacobi_apply_log_kernel<E><<<batch, threads, lds, stream>>>(W, batch_stride, 2 * n, n, n, rotlog, entries, dev, \
+                                                                    sweeps);                                          \
+    } while (0)
+    switch (epl) {
+        case 28: LAUNCH_2P(28); break;
+        case 36: LAUNCH_2P(36); break;
+        case 44: LAUNCH_2P(44); break;
+        default: LAUNCH_2P(50); break;
+    }
+#undef LAUNCH_2P
+    if (sweeps_out) {
+        hipError_t e = hipMemcpyAsync(sweeps_out, sweeps, sizeof(int) * (size_t)batch, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return (int)e;
+    }
     BASD_RETURN_LAST();
 }
 
