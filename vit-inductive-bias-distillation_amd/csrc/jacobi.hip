@@ -363,6 +363,9 @@ __global__ void __launch_bounds__(512) jacobi_top_logged_kernel(float* __restric
     }
 }
 
+// blockIdx.y = chunk of 4 EPL riding rows: rows transform independently under column rotations, so a core's riding
+// block is cut into row chunks -- several workgroups per CU whose load / rotate / store phases overlap (one workgroup
+// per core with all n rows ran at half the LDS rate: every wave in the same phase between two barriers).
 template <int EPL>
 __global__ void __launch_bounds__(512) jacobi_apply_log_kernel(float* __restrict__ W, long batch_stride, int ld, int row0,
                                                                int n, const f32x2* __restrict__ rotlog, long log_stride,
@@ -371,13 +374,14 @@ __global__ void __launch_bounds__(512) jacobi_apply_log_kernel(float* __restrict
     constexpr int LPP = TwoPassShape<EPL>::LPP, LD = TwoPassShape<EPL>::LD, H = EPL / 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    float* Wm = W + (long)m * batch_stride + row0;
+    const int r_lo = blockIdx.y * LPP * EPL, rows = n - r_lo < LPP * EPL ? n - r_lo : LPP * EPL;
+    float* Wm = W + (long)m * batch_stride + row0 + r_lo;
     const f32x2* logm = rotlog + (long)m * log_stride;
     const int n_even = (n + 1) & ~1, pairs = n_even / 2;
     for (int idx = tid; idx < n_even * LD; idx += nthr) lds[idx] = 0.f;
     __syncthreads();
-    for (int idx = tid; idx < n * n; idx += nthr) {
-        const int c = idx / n, r = idx - c * n;
+    for (int idx = tid; idx < n * rows; idx += nthr) {
+        const int c = idx / rows, r = idx - c * rows;
         lds[c * LD + r] = Wm[(long)c * ld + r];
     }
     __syncthreads();
@@ -411,8 +415,8 @@ __global__ void __launch_bounds__(512) jacobi_apply_log_kernel(float* __restrict
         cs1 = cs2;
     }
     const float* dv = dev_in + (long)m * n;
-    for (int idx = tid; idx < n * n; idx += nthr) {
-        const int c = idx / n, r = idx - c * n;
+    for (int idx = tid; idx < n * rows; idx += nthr) {
+        const int c = idx / rows, r = idx - c * rows;
         const float v = lds[c * LD + r];
         Wm[(long)c * ld + r] = fmaf(v, dv[c], v);
     }
@@ -908,12 +912,17 @@ int basd_jacobi_stacked_twopass(float* W, long batch_stride, int n, int batch, f
         if (lds > BASD_JACOBI_LDS_LIMIT) return BASD_EUNSUPPORTED;                                                    \
         (void)hipFuncSetAttribute((const void*)jacobi_top_logged_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   BASD_JACOBI_LDS_LIMIT);                                                             \
-        (void)hipFuncSetAttribute((const void*)jacobi_apply_log_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  BASD_JACOBI_LDS_LIMIT);                                                             \
         jacobi_top_logged_kernel<E><<<batch, threads, lds, stream>>>(W, batch_stride, 2 * n, n, max_sweeps, tol, colnorm, \
                                                                      colnorm_stride, rotlog, entries, dev, sweeps);   \
-        jacobi_apply_log_kernel<E><<<batch, threads, lds, stream>>>(W, batch_stride, 2 * n, n, n, rotlog, entries, dev, \
-                                                                    sweeps);                                          \
+        if (n <= 160) {                                                                                               \
+            const size_t lds2 = sizeof(float) * (size_t)n_even * TwoPassShape<10>::LD;                                \
+            jacobi_apply_log_kernel<10><<<dim3(batch, (n + 39) / 40), threads, lds2, stream>>>(                       \
+                W, batch_stride, 2 * n, n, n, rotlog, entries, dev, sweeps);                                          \
+        } else {                                                                                                      \
+            const size_t lds2 = sizeof(float) * (size_t)n_even * TwoPassShape<14>::LD;                                \
+            jacobi_apply_log_kernel<14><<<dim3(batch, (n + 55) / 56), threads, lds2, stream>>>(                       \
+                W, batch_stride, 2 * n, n, n, rotlog, entries, dev, sweeps);                                          \
+        }                                                                                                             \
     } while (0)
     switch (epl) {
         case 28: LAUNCH_2P(28); break;
