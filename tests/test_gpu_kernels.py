@@ -184,7 +184,8 @@ def test_sym_eig_block_path(dev, n):
 def test_gram_chol_f64(dev):
     from basd_amd import _lib, ops
     g = torch.Generator().manual_seed(4)
-    for n, D in [(49, 384), (196, 96), (20, 36)]:
+    # 49 / 20 / 64 / 7: one wave per matrix; 196 / 65: one workgroup per matrix; 260: panels, factor in global memory
+    for n, D in [(49, 384), (196, 96), (20, 36), (64, 80), (7, 16), (65, 80), (260, 272)]:
         p = torch.randn(3, n, D, generator=g).to(dev)
         p[2] = p[2] - p[2].mean(0, keepdim=True)      # exactly singular Gram
         G = torch.empty(3, n, n, device=dev, dtype=torch.float64)
