@@ -298,11 +298,11 @@ def main() -> None:
         if ops.EIG_SOLVER == "tridiag":
             eig_ms, eig_calls = longest(["basd_tridiag", "basd_tridiag_ranked"])
             n_mats = E if L == 1 else max(E, 2 * L)
-            kernel_name = ("tridiag_kernel + tridiag_tail_kernel (Householder tridiagonalisation of the student Gram "
+            kernel_name = ("tridiag_kernel + tridiag_tail2_kernel (Householder tridiagonalisation of the student Gram "
                            "matrices; the teacher-side call of the same entry point runs beside it)")
             note = ("latency-bound, neither an HBM stream nor MFMA work: n - 1 dependent Householder steps (first stage: "
                     "matrix shared by up to 16 workgroups, one L2 round trip + granule hand-off per step; last 256 steps: "
-                    "matrix in one CU's registers, four workgroup barriers per step).  `bound` is kept to the contract's "
+                    "matrix in one CU's registers, two workgroup barriers and one wave's scalar chain per step).  `bound` is kept to the contract's "
                     "vocabulary; the HBM fraction says how far from a stream this kernel is by construction.  The "
                     "roofline-bound kernels of the path are under roofline_mfma / roofline_hbm_stream.")
         else:
