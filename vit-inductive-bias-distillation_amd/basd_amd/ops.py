@@ -18,6 +18,7 @@ import os
 F32, BF16 = 0, 1
 MAX_SWEEPS = 20
 TWO_PASS_SVD = True      # test hook: False sends cores of 129..196 tokens through the block solver instead
+TWO_PASS_LOG_LIMIT = 16 << 30     # bytes of rotation log above which the block solver is used (cfg-4: 1.6 GB per call)
 # Symmetric eigen-solver for the selector's D_s x D_s Grams when only eigenvalues / leading eigenvectors are
 # needed: "tridiag" (Householder + bisection + inverse iteration) or "jacobi" (block one-sided Jacobi).
 EIG_SOLVER = os.environ.get("BASD_EIG_SOLVER", "tridiag")
@@ -600,6 +601,8 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
         sweeps.zero_()
     # cores whose 2n rows are past LDS while n rows fit: rotation log of the two-pass SVD (0 bytes: shape not covered)
     jac_bytes = _lib.query("basd_jacobi_twopass_workspace_bytes", n, EB, MAX_SWEEPS) if TWO_PASS_SVD else 0
+    if jac_bytes > TWO_PASS_LOG_LIMIT:       # very large batches: the block solver needs no log
+        jac_bytes = 0
     jac_ws = torch.empty((jac_bytes // 8 + 1,), device=dev, dtype=torch.int64) if jac_bytes > 0 else None
     raw = torch.empty((G, B, n_a), **f32) if need_mix_grad else None
     h = dx = uw = None
