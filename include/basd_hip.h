@@ -390,6 +390,13 @@ int basd_mix_grad_tokens(const float* r, const void* const* tok_ptrs, int dtype,
                          int E, int B, int n, int D, const int* g0, const int* g1, const float* glam, float* partial,
                          hipStream_t stream);
 
+/* The same in ONE pass over the teacher layers for all E <= 4 extraction layers (BASD_EUNSUPPORTED beyond).  scratch:
+ * basd_mix_grad_tokens_scratch_floats() floats of device memory; per-chunk sums are folded in a fixed order. */
+long basd_mix_grad_tokens_scratch_floats(int E, int B, int L, int n);
+int basd_mix_grad_tokens_onepass(const float* r, const void* const* tok_ptrs, int dtype, int L, long sb, long sn, long sd,
+                                 int E, int B, int n, int D, const int* g0, const int* g1, const float* glam,
+                                 float* partial, float* scratch, hipStream_t stream);
+
 /* partial[e][b][l] = d loss / d mix_l through the attention-derived token weights
  * (layer_selector.py:112 + relational.py:22-34). */
 int basd_token_weight_bwd(const float* gomega, const float* raw, int E, int B, int n_a, int n_s, const int* atap0,

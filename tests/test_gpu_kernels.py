@@ -607,3 +607,38 @@ def test_procrustes_two_pass_svd_matches_block_solver(dev, n_s, n_t, monkeypatch
     assert int(a.sweeps.max()) < ops.MAX_SWEEPS
     assert _rel(a.nuc, b.nuc) < 2e-6 and _rel(a.loss_b, b.loss_b) < 1e-5
     assert _rel(a.k_prime, b.k_prime) < 2e-5, _rel(a.k_prime, b.k_prime)
+
+
+@pytest.mark.parametrize("n_t, n, D, L, E, dtype", [
+    (196, 196, 96, 24, 4, torch.float32),      # cfg-4's layer count: three passes of 8 layers
+    (100, 100, 40, 5, 3, torch.float32),       # last chunk of 4 rows, partial layer group
+    (256, 64, 48, 3, 2, torch.bfloat16),       # finer teacher grid gathered to 64 tokens, bf16 rows
+])
+def test_mix_grad_tokens_onepass_matches_per_layer(dev, n_t, n, D, L, E, dtype):
+    """basd_mix_grad_tokens_onepass (all extraction layers, one pass over the teacher layers, per-chunk sums folded in
+    a fixed order) against basd_mix_grad_tokens and an fp64 evaluation of <R[e][b], That_l[b]>
+    (layer_selector.py:111)."""
+    from basd_amd import ops, _lib
+    g = torch.Generator().manual_seed(n_t * 3 + L)
+    B = 3
+    full = [torch.randn(B, n_t + 1, D, generator=g).to(dev).to(dtype) for _ in range(L)]
+    toks = [f[:, 1:, :] for f in full]
+    R = torch.randn(E, B, n, D, generator=g).to(dev)
+    gt = ops.taps(n_t, n, dev) if n_t != n else None
+    g0, g1, gl = (gt.tap0.data_ptr(), gt.tap1.data_ptr(), gt.lam.data_ptr()) if gt else (None, None, None)
+    tab = ops._ptr_table(toks)
+    sb, sn, sd = toks[0].stride()
+    p1 = torch.empty(E, B, L, device=dev)
+    p2 = torch.empty_like(p1)
+    _lib.call("basd_mix_grad_tokens", R.data_ptr(), tab.data_ptr(), ops._dtype_code(toks[0]), L, sb, sn, sd, E, B, n, D,
+              g0, g1, gl, p1.data_ptr(), ops._stream())
+    scratch = torch.empty((_lib.query("basd_mix_grad_tokens_scratch_floats", E, B, L, n),), device=dev)
+    _lib.call("basd_mix_grad_tokens_onepass", R.data_ptr(), tab.data_ptr(), ops._dtype_code(toks[0]), L, sb, sn, sd, E, B,
+              n, D, g0, g1, gl, p2.data_ptr(), scratch.data_ptr(), ops._stream())
+    torch.cuda.synchronize()
+    T = torch.stack([t.double() for t in toks])                                   # (L, B, n_t, D)
+    if gt is not None:
+        lam = gt.lam.double()[None, None, :, None]
+        T = (1 - lam) * T[:, :, gt.tap0.long()] + lam * T[:, :, gt.tap1.long()]
+    ref = torch.einsum("ebjd,lbjd->ebl", R.double(), T)
+    assert _rel(p2, ref) < 1e-5 and _rel(p1, ref) < 1e-5, (_rel(p2, ref), _rel(p1, ref))

@@ -74,6 +74,8 @@ SIGNATURES = {
     "basd_teacher_factor": [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "basd_teacher_factor_tiled": [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "basd_mix_grad_tokens": [vp, vp, i32, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "basd_mix_grad_tokens_scratch_floats": [i32, i32, i32, i32],
+    "basd_mix_grad_tokens_onepass": [vp, vp, i32, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
     "basd_token_weight_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, i64, i32,
                               i32, i32, vp, vp, vp],
     "basd_build_angle_stack": [vp, i32, vp, i32, vp, vp],
@@ -104,7 +106,8 @@ class ProcrustesArgs(C.Structure):
 EINVAL, EUNSUPPORTED = -1, -2        # BASD_EINVAL / BASD_EUNSUPPORTED of include/basd_hip.h
 
 # sizing helpers declared `long` in include/basd_hip.h
-LONG_RESULTS = {"basd_tridiag_workspace_bytes", "basd_jacobi_twopass_workspace_bytes"}
+LONG_RESULTS = {"basd_tridiag_workspace_bytes", "basd_jacobi_twopass_workspace_bytes",
+                "basd_mix_grad_tokens_scratch_floats"}
 
 _lock = threading.Lock()
 _lib = None

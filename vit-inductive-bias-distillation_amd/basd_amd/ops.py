@@ -751,8 +751,15 @@ def procrustes_mix_grads(ctx: ProcrustesContext, kt: torch.Tensor, gomega: torch
     g0, g1, glam = (gt.tap0.data_ptr(), gt.tap1.data_ptr(), gt.lam.data_ptr()) if gt else (None, None, None)
     part_tok = torch.empty((E, B, L), device=dev, dtype=torch.float32)
     tsb, tsn, tsd = teachers[0].stride()
-    _lib.call("basd_mix_grad_tokens", r.data_ptr(), mg["tok_tab"].data_ptr(), _dtype_code(teachers[0]), L, tsb, tsn,
-              tsd, E, B, n, d_t, g0, g1, glam, part_tok.data_ptr(), st)
+    if E <= 4 and L > 1:
+        # all extraction layers in one pass over the teacher layers
+        scratch = torch.empty((_lib.query("basd_mix_grad_tokens_scratch_floats", E, B, L, n),), device=dev,
+                              dtype=torch.float32)
+        _lib.call("basd_mix_grad_tokens_onepass", r.data_ptr(), mg["tok_tab"].data_ptr(), _dtype_code(teachers[0]), L,
+                  tsb, tsn, tsd, E, B, n, d_t, g0, g1, glam, part_tok.data_ptr(), scratch.data_ptr(), st)
+    else:
+        _lib.call("basd_mix_grad_tokens", r.data_ptr(), mg["tok_tab"].data_ptr(), _dtype_code(teachers[0]), L, tsb,
+                  tsn, tsd, E, B, n, d_t, g0, g1, glam, part_tok.data_ptr(), st)
     atp = mg["attn_taps"]
     a0, a1, alam = (atp.tap0.data_ptr(), atp.tap1.data_ptr(), atp.lam.data_ptr()) if atp else (None, None, None)
     ar0, ar1 = (atp.range0.data_ptr(), atp.range1.data_ptr()) if atp else (None, None)

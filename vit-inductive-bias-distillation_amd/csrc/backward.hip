@@ -223,6 +223,79 @@ __global__ void __launch_bounds__(256) mix_grad_tokens_kernel(const float* __res
     if (threadIdx.x == 0) partial[((long)e * B + b) * L + l] = acc;
 }
 
+// The same in ONE pass over the teacher layers for all E <= 4 extraction layers (the kernel above reads every layer
+// once per extraction layer and R once per teacher layer: 20 GB through L2 per step at cfg-4 for 2.9 GB of operands).
+// A workgroup owns MG_ROWS token rows of one sample and walks the layers MG_LT at a time with E x MG_LT accumulators per
+// thread; per-chunk sums go to `chunk_part` (chunks, E, B, L) and are folded in a fixed order by mix_grad_fold_kernel.
+// grid = (chunks, B), block = 256.
+constexpr int MG_ROWS = 16, MG_LT = 8, MG_E = 4;
+template <typename T>
+__global__ void __launch_bounds__(256) mix_grad_tokens_onepass_kernel(
+    const float* __restrict__ R, const void* const* __restrict__ tok_ptrs, long sb, long sn, long sd, int E, int L, int n,
+    int D, const int* __restrict__ g0, const int* __restrict__ g1, const float* __restrict__ glam,
+    float* __restrict__ chunk_part) {
+    __shared__ float red[4][MG_E * MG_LT];
+    const int chunk = blockIdx.x, b = blockIdx.y, B = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j_lo = chunk * MG_ROWS, j_hi = j_lo + MG_ROWS < n ? j_lo + MG_ROWS : n;
+    const int count = (j_hi - j_lo) * D;
+    for (int l0 = 0; l0 < L; l0 += MG_LT) {
+        float acc[MG_E][MG_LT];
+#pragma unroll
+        for (int e = 0; e < MG_E; ++e)
+#pragma unroll
+            for (int u = 0; u < MG_LT; ++u) acc[e][u] = 0.f;
+        const BASD_GLOBAL_AS T* tp[MG_LT];
+#pragma unroll
+        for (int u = 0; u < MG_LT; ++u)
+            tp[u] = (const BASD_GLOBAL_AS T*)tok_ptrs[l0 + u < L ? l0 + u : L - 1] + (long)b * sb;
+        for (int idx = tid; idx < count; idx += 256) {
+            const int jj = idx / D, d = idx - jj * D, j = j_lo + jj;
+            float rv[MG_E];
+#pragma unroll
+            for (int e = 0; e < MG_E; ++e) rv[e] = e < E ? R[(((long)e * B + b) * n + j) * D + d] : 0.f;
+            long o0 = (long)j * sn + (long)d * sd, o1 = o0;
+            float l1 = 0.f;
+            if (g0) {
+                o0 = (long)g0[j] * sn + (long)d * sd;
+                o1 = (long)g1[j] * sn + (long)d * sd;
+                l1 = glam[j];
+            }
+#pragma unroll
+            for (int u = 0; u < MG_LT; ++u) {
+                float tv = ldg_f32(tp[u] + o0);
+                if (g0) tv = (1.f - l1) * tv + l1 * ldg_f32(tp[u] + o1);
+#pragma unroll
+                for (int e = 0; e < MG_E; ++e) acc[e][u] = fmaf(rv[e], tv, acc[e][u]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < MG_E; ++e)
+#pragma unroll
+            for (int u = 0; u < MG_LT; ++u) {
+                float v = acc[e][u];
+                for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+                if (lane == 0) red[wave][e * MG_LT + u] = v;
+            }
+        __syncthreads();
+        if (tid < MG_E * MG_LT) {
+            const int e = tid / MG_LT, u = tid - e * MG_LT;
+            if (e < E && l0 + u < L)
+                chunk_part[(((long)chunk * E + e) * B + b) * L + l0 + u] =
+                    (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) mix_grad_fold_kernel(const float* __restrict__ chunk_part, int chunks, long count,
+                                                            float* __restrict__ partial) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc += chunk_part[(long)c * count + i];
+    partial[i] = acc;
+}
+
 // ---------------------------------------------------------------------------
 // Chain d loss / d omega back to the mixing weights through relational.py:22-34 and layer_selector.py:112:
 // normalisation, weight interpolation (n_a -> n_s), head / query mean, layer mix.
@@ -454,6 +527,29 @@ int basd_mix_grad_tokens(const float* r, const void* const* tok_ptrs, int dtype,
         mix_grad_tokens_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(r, tok_ptrs, sb, sn, sd, n, D, g0, g1, glam, partial);
     else
         return BASD_EINVAL;
+    BASD_RETURN_LAST();
+}
+
+// The same in one pass over the teacher layers (E <= 4).  scratch: basd_mix_grad_tokens_scratch_floats(E, B, L, n) floats.
+long basd_mix_grad_tokens_scratch_floats(int E, int B, int L, int n) {
+    if (E <= 0 || B <= 0 || L <= 0 || n <= 0) return 0;
+    return (long)((n + MG_ROWS - 1) / MG_ROWS) * E * B * L;
+}
+int basd_mix_grad_tokens_onepass(const float* r, const void* const* tok_ptrs, int dtype, int L, long sb, long sn, long sd,
+                                 int E, int B, int n, int D, const int* g0, const int* g1, const float* glam,
+                                 float* partial, float* scratch, hipStream_t stream) {
+    BASD_CHECK_ARG(r && tok_ptrs && partial && scratch && L > 0 && E > 0 && B > 0 && n > 0 && D > 0);
+    if (E > MG_E || B > 65535) return BASD_EUNSUPPORTED;
+    const int chunks = (n + MG_ROWS - 1) / MG_ROWS;
+    const dim3 grid(chunks, B);
+    if (dtype == BASD_DTYPE_F32)
+        mix_grad_tokens_onepass_kernel<float><<<grid, 256, 0, stream>>>(r, tok_ptrs, sb, sn, sd, E, L, n, D, g0, g1, glam, scratch);
+    else if (dtype == BASD_DTYPE_BF16)
+        mix_grad_tokens_onepass_kernel<__hip_bfloat16><<<grid, 256, 0, stream>>>(r, tok_ptrs, sb, sn, sd, E, L, n, D, g0, g1, glam, scratch);
+    else
+        return BASD_EINVAL;
+    const long count = (long)E * B * L;
+    mix_grad_fold_kernel<<<(unsigned)((count + 255) / 256), 256, 0, stream>>>(scratch, chunks, count, partial);
     BASD_RETURN_LAST();
 }
 
