@@ -249,6 +249,14 @@ int basd_teacher_center(const void* const* tok_ptrs, int dtype, const float* mix
 int basd_teacher_center_multi(const void* const* tok_ptrs, int dtype, const float* mix, int L, int G, long sb, long sn,
                               long sd, int B, int n, int D, const int* g0, const int* g1, const float* glam,
                               const float* omega_t, float* mu, float* tc, hipStream_t stream);
+/* Streaming form of the same for row-major teacher tokens and many layers (no LDS tile: full rows are read; the mixed
+ * tokens are written uncentred with per-chunk weighted column sums, a second pass folds the sums in a fixed order and
+ * subtracts the mean in place).  scratch: basd_teacher_center_stream_scratch_floats() floats.  BASD_EUNSUPPORTED: more
+ * than 4 groups or features not contiguous (sd != 1). */
+long basd_teacher_center_stream_scratch_floats(int G, int B, int n, int D);
+int basd_teacher_center_stream(const void* const* tok_ptrs, int dtype, const float* mix, int L, int G, long sb, long sn,
+                               long sd, int B, int n, int D, const int* g0, const int* g1, const float* glam,
+                               const float* omega_t, float* mu, float* tc, float* scratch, hipStream_t stream);
 
 /* G[b] = P[b] P[b]^T accumulated in fp64 on v_mfma_f64_16x16x4_f64 (the bmm of relational.py:47,
  * reduced to the teacher grid). */

@@ -551,6 +551,14 @@ def test_teacher_center_multi_matches_per_group(dev, n_t, n, D, L, G, layout, dt
                   sd, B, n, D, g0, g1, gl, omega_t.data_ptr(), mu2.data_ptr(), tc2.data_ptr(), ops._stream())
     torch.cuda.synchronize()
     assert _rel(mu2, mu1) < 1e-5 and _rel(tc2, tc1) < 1e-5, (_rel(mu2, mu1), _rel(tc2, tc1))
+    if layout == "row":      # the streaming form (no LDS tile, per-chunk column sums folded in a second pass)
+        mu3, tc3 = torch.empty_like(mu1), torch.empty_like(tc1)
+        scratch = torch.empty((ops._lib.query("basd_teacher_center_stream_scratch_floats", G, B, n, D),), device=dev)
+        ops._lib.call("basd_teacher_center_stream", tab.data_ptr(), ops._dtype_code(toks[0]), mix.data_ptr(), L, G, sb,
+                      sn, sd, B, n, D, g0, g1, gl, omega_t.data_ptr(), mu3.data_ptr(), tc3.data_ptr(),
+                      scratch.data_ptr(), ops._stream())
+        torch.cuda.synchronize()
+        assert _rel(mu3, mu1) < 1e-5 and _rel(tc3, tc1) < 1e-5, (_rel(mu3, mu1), _rel(tc3, tc1))
 
 
 @pytest.mark.parametrize("n, batch", [(144, 3), (196, 2), (130, 2), (177, 2), (190, 2)])

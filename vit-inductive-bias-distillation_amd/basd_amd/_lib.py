@@ -55,6 +55,8 @@ SIGNATURES = {
     "basd_student_project": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "basd_teacher_center": [vp, i32, vp, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_teacher_center_multi": [vp, i32, vp, i32, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+    "basd_teacher_center_stream_scratch_floats": [i32, i32, i32, i32],
+    "basd_teacher_center_stream": [vp, i32, vp, i32, i32, i64, i64, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "basd_gram_f64": [vp, i64, i32, i32, i32, vp, i64, vp],
     "basd_gram_f64_split": [vp, i64, i32, i32, i32, i32, vp, vp, vp],
     "basd_chol_f64": [vp, i64, i32, i32, vp, i64, vp],
@@ -107,7 +109,7 @@ EINVAL, EUNSUPPORTED = -1, -2        # BASD_EINVAL / BASD_EUNSUPPORTED of includ
 
 # sizing helpers declared `long` in include/basd_hip.h
 LONG_RESULTS = {"basd_tridiag_workspace_bytes", "basd_jacobi_twopass_workspace_bytes",
-                "basd_mix_grad_tokens_scratch_floats"}
+                "basd_mix_grad_tokens_scratch_floats", "basd_teacher_center_stream_scratch_floats"}
 
 _lock = threading.Lock()
 _lib = None

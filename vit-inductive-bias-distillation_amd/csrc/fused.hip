@@ -92,7 +92,14 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
                                     a->omega_t + (long)g * B * n, a->raw ? a->raw + (long)g * B * n_a : nullptr, st));
     }
     // mixed, centred teacher: all groups in one pass over the teacher layers where that applies
-    if (G > 1) {
+    if (G > 1 && L >= 4 && basd_teacher_center_stream_scratch_floats(G, B, n, d_t) <= (long)E * B * 2 * n * n) {
+        // many layers: the streaming form; its per-chunk column sums borrow W, which is not written before the stacked
+        // product
+        centred = basd_teacher_center_stream(a->tok_ptrs, (int)a->t_dtype, a->mix, L, G, a->t_sb, a->t_sn, a->t_sd, B, n,
+                                             d_t, a->g0, a->g1, a->glam, a->omega_t, a->mu_t, a->tc, a->W, st);
+        if (centred != BASD_OK && centred != BASD_EUNSUPPORTED) return centred;
+    }
+    if (G > 1 && centred != BASD_OK) {
         centred = basd_teacher_center_multi(a->tok_ptrs, (int)a->t_dtype, a->mix, L, G, a->t_sb, a->t_sn, a->t_sd, B, n,
                                             d_t, a->g0, a->g1, a->glam, a->omega_t, a->mu_t, a->tc, st);
         if (centred != BASD_OK && centred != BASD_EUNSUPPORTED) return centred;

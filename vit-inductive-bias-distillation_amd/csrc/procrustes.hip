@@ -489,6 +489,66 @@ __global__ void __launch_bounds__(256) teacher_center_multi_kernel(
     }
 }
 
+// Streaming form of the same (row-major teacher tokens, many layers: cfg-4 mixes 24 ViT-L layers for 4 groups): no LDS
+// tile, so full rows are read -- pass 1 writes the mixed tokens uncentred and leaves, per chunk of TCS_ROWS rows, the
+// weighted column sums (each thread owns its feature columns: no cross-thread reduction); pass 2 folds the chunk sums
+// in a fixed order into the weighted mean and subtracts it in place.  2.5 GB read once + 0.4 GB written + 0.8 GB for
+// the centring pass at cfg-4, against 64-byte row segments through a 16-feature LDS tile in the kernel above.
+// pass 1: grid = (chunks, B), block = 256.  pass 2: grid = (ceil(D / 256), chunks, G * B), block = 256.
+constexpr int TCS_ROWS = 16;
+template <typename T>
+__global__ void __launch_bounds__(256) teacher_mix_stream_kernel(
+    const void* const* __restrict__ tok_ptrs, const float* __restrict__ mix, int L, int G, long sb, long sn, long sd, int n,
+    int D, const int* __restrict__ g0, const int* __restrict__ g1, const float* __restrict__ glam,
+    const float* __restrict__ omega_t, float* __restrict__ Tc, float* __restrict__ chunk_sum) {
+    const int chunk = blockIdx.x, b = blockIdx.y, B = gridDim.y, tid = threadIdx.x;
+    const int j_lo = chunk * TCS_ROWS, j_hi = j_lo + TCS_ROWS < n ? j_lo + TCS_ROWS : n;
+    for (int d = tid; d < D; d += 256) {
+        float musum[TCM_G] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = j_lo; j < j_hi; ++j) {
+            long o0 = b * sb + (long)j * sn + (long)d * sd, o1 = o0;
+            float l1 = 0.f;
+            if (g0) {
+                o0 = b * sb + (long)g0[j] * sn + (long)d * sd;
+                o1 = b * sb + (long)g1[j] * sn + (long)d * sd;
+                l1 = glam[j];
+            }
+            float v[TCM_G] = {0.f, 0.f, 0.f, 0.f};
+            for (int l = 0; l < L; ++l) {
+                const BASD_GLOBAL_AS T* p = (const BASD_GLOBAL_AS T*)tok_ptrs[l];
+                float x = ldg_f32(p + o0);
+                if (g0) x = (1.f - l1) * x + l1 * ldg_f32(p + o1);
+#pragma unroll
+                for (int g = 0; g < TCM_G; ++g)
+                    if (g < G) v[g] = fmaf(mix[g * L + l], x, v[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < TCM_G; ++g)
+                if (g < G) {
+                    Tc[(((long)g * B + b) * n + j) * D + d] = v[g];
+                    musum[g] = fmaf(omega_t[((long)g * B + b) * n + j], v[g], musum[g]);
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < TCM_G; ++g)
+            if (g < G) chunk_sum[(((long)chunk * G + g) * B + b) * D + d] = musum[g];
+    }
+}
+
+__global__ void __launch_bounds__(256) teacher_center_apply_kernel(const float* __restrict__ chunk_sum, int chunks, int n,
+                                                                   int D, float* __restrict__ mu_out,
+                                                                   float* __restrict__ Tc) {
+    const int d = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
+    const long gb = blockIdx.z, GB = gridDim.z;
+    if (d >= D) return;
+    float mu = 0.f;
+    for (int c = 0; c < chunks; ++c) mu += chunk_sum[((long)c * GB + gb) * D + d];
+    if (chunk == 0) mu_out[gb * D + d] = mu;
+    const int j_lo = chunk * TCS_ROWS, j_hi = j_lo + TCS_ROWS < n ? j_lo + TCS_ROWS : n;
+    float* out = Tc + gb * n * D + d;
+    for (int j = j_lo; j < j_hi; ++j) out[(long)j * D] -= mu;
+}
+
 // ---------------------------------------------------------------------------
 // Batched Gram in fp64 on the f64 MFMA: G[b] = P[b] P[b]^T, P: (n x D) fp32 row-major.
 // grid = batch, block = 64 * waves.  Lower tiles (16 x 16) are dealt round-robin to waves.
@@ -1226,6 +1286,30 @@ int basd_teacher_center_multi(const void* const* tok_ptrs, int dtype, const floa
     } else {
         return BASD_EINVAL;
     }
+    BASD_RETURN_LAST();
+}
+
+// Streaming form of basd_teacher_center_multi for row-major teacher tokens (see teacher_mix_stream_kernel): scratch of
+// basd_teacher_center_stream_scratch_floats(G, B, n, D) floats.  BASD_EUNSUPPORTED: more than 4 groups, features not
+// contiguous.
+long basd_teacher_center_stream_scratch_floats(int G, int B, int n, int D) {
+    if (G <= 0 || B <= 0 || n <= 0 || D <= 0) return 0;
+    return (long)((n + TCS_ROWS - 1) / TCS_ROWS) * G * B * D;
+}
+int basd_teacher_center_stream(const void* const* tok_ptrs, int dtype, const float* mix, int L, int G, long sb, long sn,
+                               long sd, int B, int n, int D, const int* g0, const int* g1, const float* glam,
+                               const float* omega_t, float* mu, float* tc, float* scratch, hipStream_t stream) {
+    BASD_CHECK_ARG(tok_ptrs && mix && omega_t && mu && tc && scratch && L > 0 && G > 0 && B > 0 && n > 0 && D > 0);
+    BASD_CHECK_ARG((g0 == nullptr) == (g1 == nullptr) && (g0 == nullptr) == (glam == nullptr));
+    if (G > TCM_G || sd != 1 || B > 65535 || (long)G * B > 65535) return BASD_EUNSUPPORTED;
+    const int chunks = (n + TCS_ROWS - 1) / TCS_ROWS;
+    if (dtype == BASD_DTYPE_F32)
+        teacher_mix_stream_kernel<float><<<dim3(chunks, B), 256, 0, stream>>>(tok_ptrs, mix, L, G, sb, sn, sd, n, D, g0, g1, glam, omega_t, tc, scratch);
+    else if (dtype == BASD_DTYPE_BF16)
+        teacher_mix_stream_kernel<__hip_bfloat16><<<dim3(chunks, B), 256, 0, stream>>>(tok_ptrs, mix, L, G, sb, sn, sd, n, D, g0, g1, glam, omega_t, tc, scratch);
+    else
+        return BASD_EINVAL;
+    teacher_center_apply_kernel<<<dim3((D + 255) / 256, chunks, G * B), 256, 0, stream>>>(scratch, chunks, n, D, mu, tc);
     BASD_RETURN_LAST();
 }
 
