@@ -95,6 +95,9 @@ int basd_syrk_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long
 /* ---- one-sided Jacobi SVD / symmetric eigensolver ------------------------------------------ */
 
 int basd_jacobi_workspace_ints(int batch, int max_sweeps);
+/* 1 when basd_jacobi_onesided takes large batches of plain n x n matrices with 4 lanes per column pair in LDS (orders
+ * 40..144): basd_procrustes_forward_fused then solves the TRANSPOSED cores, without riding rows. */
+int basd_jacobi_plain4_fits(int n);
 
 /* In-place one-sided Jacobi on `batch` column-major matrices (rows_tot x n, leading dim rows_tot):
  * right rotations orthogonalise the first rows_dot rows; colnorm receives the column norms.
@@ -357,6 +360,20 @@ typedef struct BasdProcrustesArgs {
     void* jac_ws;
 } BasdProcrustesArgs;
 int basd_procrustes_forward_fused(const BasdProcrustesArgs* args, hipStream_t stream);
+/* Test / tuning hook: 0 = always the stacked cores [M; L_b] (riding rows); 1 = the transposed cores where they apply
+ * (default: no gradient through the mixing weights, >= 128 cores, basd_jacobi_plain4_fits(n)); 2 = the same for any
+ * batch; negative = keep.  Process-wide. */
+int basd_procrustes_tuning(int transposed_cores);
+
+/* The two pieces of the transposed route (relational.py:47-48 and its autograd): M = L_a^T L_b alone, row-major and
+ * compact at w + b * w_batch_stride -- as a column-major matrix that is M^T, whose one-sided Jacobi leaves V Sigma in
+ * the columns -- and K' = Y Sigma^+ Y^T with Y = L_b V formed from those columns (z: n x n floats of scratch per
+ * matrix at z + b * z_batch_stride). */
+int basd_stack_product_t(const double* la, const double* lb, long l_batch_stride, int n, int batch, int lb_period,
+                         float* w, long w_batch_stride, hipStream_t stream);
+int basd_kprime_from_transposed(const float* w, long w_batch_stride, const float* sigma, int n, int batch,
+                                const double* lb, long l_batch_stride, int lb_period, float* z, long z_batch_stride,
+                                float* k_prime, hipStream_t stream);
 
 /* x *= num / den unless the ratio is exactly 1 (then the launch returns at once): the upstream gradient of a loss that
  * was differentiated for a unit one.  num, den: one fp32 each on the device, den nullable (= 1). */

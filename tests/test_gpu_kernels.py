@@ -650,3 +650,50 @@ def test_mix_grad_tokens_onepass_matches_per_layer(dev, n_t, n, D, L, E, dtype):
         T = (1 - lam) * T[:, :, gt.tap0.long()] + lam * T[:, :, gt.tap1.long()]
     ref = torch.einsum("ebjd,lbjd->ebl", R.double(), T)
     assert _rel(p2, ref) < 1e-5 and _rel(p1, ref) < 1e-5, (_rel(p2, ref), _rel(p1, ref))
+
+
+@pytest.mark.parametrize("n_s, n_t, d_s, d_t, E, B", [
+    (196, 49, 384, 512, 2, 3),       # cfg-2's cores
+    (576, 144, 256, 320, 1, 3),      # cfg-5's: one plain LDS solve instead of the two-pass SVD
+    (64, 64, 192, 256, 2, 2),        # no interpolation
+    (100, 100, 48, 64, 1, 2),        # rank-deficient cores (47 < 100): truncated singular values
+])
+def test_transposed_cores_match_the_stacked_route(dev, n_s, n_t, d_s, d_t, E, B):
+    """The route without riding rows (Jacobi on M^T leaves V Sigma; Y = L_b V formed with K') against the stacked cores
+    [M; L_b] on the same inputs: per-sample terms, K' and the student gradients (relational.py:36-50 and autograd)."""
+    from basd_amd import ops, synth, _lib
+    g = torch.Generator().manual_seed(n_s + 7 * n_t)
+    students = [synth.structured(g, B, n_s, d_s, 16).to(dev) for _ in range(E)]
+    t = synth.structured(g, B, n_t, d_t, 12).to(dev)
+    attn = torch.softmax(torch.randn(B, 2, n_t, n_t, generator=g), dim=-1).to(dev)
+    mix = torch.ones(E, 1, device=dev)
+    gl = torch.rand(E, generator=g).to(dev) + 0.5
+    out = {}
+    try:
+        for mode in (0, 2):
+            _lib.call("basd_procrustes_tuning", mode)
+            pc = ops.procrustes_forward(students, [t], [attn], mix, False, want_sweeps=True, grad_layers=gl)
+            torch.cuda.synchronize()
+            out[mode] = pc
+    finally:
+        _lib.call("basd_procrustes_tuning", 1)
+    a, b = out[2], out[0]
+    assert 0 < int(a.sweeps.max()) < ops.MAX_SWEEPS
+    assert _rel(a.nuc, b.nuc) < 2e-6 and _rel(a.loss_b, b.loss_b) < 1e-5
+    # K' carries 1 / sigma: both routes have fp32 round-off there (1e-5; 1e-4 with singular values near the truncation
+    # threshold), so each is held to the fp64 gradient rather than to the other
+    assert _rel(a.k_prime, b.k_prime) < 3e-4, _rel(a.k_prime, b.k_prime)
+    from oracle import basd_oracle as O
+    w = O.token_weights(attn.cpu(), False, n_s).double()
+    t_al = O.resample_tokens(t.cpu(), n_s).double()
+    w3 = w.unsqueeze(-1)
+    t_w = w3.sqrt() * (t_al - (w3 * t_al).sum(1, keepdim=True))
+    for e in range(E):
+        s64 = students[e].double().cpu().requires_grad_(True)
+        s_w = w3.sqrt() * (s64 - (w3 * s64).sum(1, keepdim=True))
+        ref = (s_w.square().sum((1, 2)) + t_w.square().sum((1, 2))
+               - 2 * torch.linalg.svdvals(torch.bmm(s_w.transpose(1, 2), t_w)).sum(-1)).mean() * gl[e].item()
+        ref.backward()
+        for pc in (a, b):
+            err = ((pc.dx[e].double().cpu() - s64.grad).norm() / s64.grad.norm()).item()
+            assert err < 1e-4, (e, err)

@@ -70,6 +70,10 @@ SIGNATURES = {
     "basd_student_grad_fused": [vp, i32, i64, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp, vp, vp, vp, vp,
                                 f32, vp, vp],
     "basd_procrustes_forward_fused": [vp, vp],
+    "basd_procrustes_tuning": [i32],
+    "basd_jacobi_plain4_fits": [i32],
+    "basd_stack_product_t": [vp, vp, i64, i32, i32, i32, vp, i64, vp],
+    "basd_kprime_from_transposed": [vp, i64, vp, i32, i32, vp, i64, i32, vp, i64, vp, vp],
     "basd_resample_tokens": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "basd_resample_tokens_adjoint": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_student_grad": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp],

@@ -70,12 +70,52 @@ int basd_scale_unless_one(float* x, long count, const float* num, const float* d
     BASD_RETURN_LAST();
 }
 
+// combined.py:76-85 and the student gradients: the end of basd_procrustes_forward_fused, shared by its two SVD routes.
+static int procrustes_tail(const BasdProcrustesArgs* a, const float* grad_layers, int E, int B, int n_s, int n, int d_s,
+                           int EB, long nn, long om_stride, hipStream_t st) {
+    int rc;
+#define BASD_TRY(call)            \
+    do {                          \
+        rc = (call);              \
+        if (rc != BASD_OK) return rc; \
+    } while (0)
+    // combined.py:76-85: the UW-SO weights and the total, on the device (the student gradients below are then final)
+    if (a->uw_ce) {
+        BASD_CHECK_ARG(a->uw_out != nullptr);
+        basd::uwso_combine_kernel<<<1, 256, 0, st>>>(a->uw_ce, a->loss_b, E, B, a->uw_out);
+        grad_layers = a->uw_out + 4;
+    }
+    // student gradients for the upstream gradients grad_layers (E floats on the device): H = K' A', then one pass
+    if (a->dx) {
+        BASD_CHECK_ARG(a->k_prime && a->h && grad_layers);
+        rc = basd_student_grad_fused(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s,
+                                     (int)a->s_aligned, a->omega, om_stride, a->mu_s, a->k_prime, a->a_prime, a->tap0,
+                                     a->tap1, a->lam, grad_layers, 2.0f / (float)B, a->dx, st);
+        if (rc != BASD_EUNSUPPORTED) return rc;
+        BASD_TRY(basd_gemm_tn(a->k_prime, a->a_prime, BASD_DTYPE_F32, 0, n, 1, nn, 0, d_s, 1, (long)n * d_s, 1 << 30, n,
+                              n, d_s, EB, nullptr, nullptr, 1, nullptr, a->h, d_s, (long)n * d_s, 1.f, st));
+        BASD_TRY(basd_student_grad_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s, a->omega,
+                                         om_stride, a->mu_s, a->h, a->tap0, a->tap1, a->lam, grad_layers,
+                                         2.0f / (float)B, a->dx, nullptr, nullptr, st));
+    }
+#undef BASD_TRY
+    return BASD_OK;
+}
+
+// Test hook: 0 keeps the stacked cores [M; L_b] (riding rows) for every shape, 2 drops the batch threshold.
+static int g_transposed_cores = 1;
+int basd_procrustes_tuning(int transposed_cores) {
+    if (transposed_cores >= 0) g_transposed_cores = transposed_cores > 2 ? 2 : transposed_cores;
+    return BASD_OK;
+}
+
 // relational.py:22-50 for all extraction layers against the (mixed) teacher, forward and -- optionally -- the student
 // gradients for given upstream gradients; see BasdProcrustesArgs in include/basd_hip.h.
 int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
     BASD_CHECK_ARG(a && a->student_ptrs && a->tok_ptrs && a->attn_ptrs && a->mix);
     const int E = (int)a->E, L = (int)a->L, G = (int)a->G, B = (int)a->B, n_s = (int)a->n_s, n_t = (int)a->n_t;
     const int d_s = (int)a->d_s, d_t = (int)a->d_t, H = (int)a->H, A = (int)a->A, n_a = (int)a->n_a, n = (int)a->n;
+    const float* grad_layers_in = a->grad_layers;
     BASD_CHECK_ARG(E > 0 && L > 0 && (G == 1 || G == E) && B > 0 && n == (n_s < n_t ? n_s : n_t));
     int rc;
 #define BASD_TRY(call)            \
@@ -135,6 +175,22 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
     else
         BASD_TRY(basd_gram_f64(a->tc, (long)n * d_t, n, d_t, GB, a->g_all + (long)EB * nn, nn, st));
     BASD_TRY(basd_chol_f64(a->g_all, nn, n, EB + GB, a->l_all, nn, st));
+    // Cores that the plain 4-lane LDS solver takes, when nothing needs U Sigma afterwards (no gradient through the
+    // mixing weights): the Jacobi runs on M^T alone -- its columns come out as V Sigma -- and Y = L_b V is formed when K'
+    // is (half the rows per pair-step, no two-pass / block solver at cfg-5's 144 tokens).
+    if (a->raw == nullptr && EB <= 65535 && basd_jacobi_plain4_fits(n) &&
+        (g_transposed_cores == 2 || (g_transposed_cores == 1 && EB >= 128))) {
+        BASD_TRY(basd_stack_product_t(a->l_all, a->l_all + (long)EB * nn, nn, n, EB, GB, a->W, 2 * nn, st));
+        BASD_TRY(basd_jacobi_onesided(a->W, 2 * nn, n, n, n, EB, nullptr, a->sigma, n, (int)a->max_sweeps, 0.f,
+                                      a->jflags, a->sweeps, st));
+        BASD_TRY(basd_procrustes_finalize(a->W, 2 * nn, a->sigma, n, n_s, EB, GB, a->g_all + (long)EB * nn, nn, a->omega,
+                                          a->tap0, a->tap1, a->lam, a->tr_part, slabs, a->tr_s, a->tr_t, a->nuc,
+                                          a->loss_b, nullptr, st));
+        if (a->k_prime)
+            BASD_TRY(basd_kprime_from_transposed(a->W, 2 * nn, a->sigma, n, EB, a->l_all + (long)EB * nn, nn, GB,
+                                                 a->W + nn, 2 * nn, a->k_prime, st));
+        return procrustes_tail(a, grad_layers_in, E, B, n_s, n, d_s, EB, nn, om_stride, st);
+    }
     BASD_TRY(basd_stack_product(a->l_all, a->l_all + (long)EB * nn, nn, n, EB, GB, a->W, 2 * nn, st));
     rc = BASD_EUNSUPPORTED;
     if (a->jac_ws)
@@ -147,28 +203,8 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
     BASD_TRY(basd_procrustes_finalize(a->W, 2 * nn, a->sigma, n, n_s, EB, GB, a->g_all + (long)EB * nn, nn, a->omega,
                                       a->tap0, a->tap1, a->lam, a->tr_part, slabs, a->tr_s, a->tr_t, a->nuc,
                                       a->loss_b, a->k_prime, st));
-    // combined.py:76-85: the UW-SO weights and the total, on the device (the student gradients below are then final)
-    const float* grad_layers = a->grad_layers;
-    if (a->uw_ce) {
-        BASD_CHECK_ARG(a->uw_out != nullptr);
-        basd::uwso_combine_kernel<<<1, 256, 0, st>>>(a->uw_ce, a->loss_b, E, B, a->uw_out);
-        grad_layers = a->uw_out + 4;
-    }
-    // student gradients for the upstream gradients grad_layers (E floats on the device): H = K' A', then one pass
-    if (a->dx) {
-        BASD_CHECK_ARG(a->k_prime && a->h && grad_layers);
-        rc = basd_student_grad_fused(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s,
-                                     (int)a->s_aligned, a->omega, om_stride, a->mu_s, a->k_prime, a->a_prime, a->tap0,
-                                     a->tap1, a->lam, grad_layers, 2.0f / (float)B, a->dx, st);
-        if (rc != BASD_EUNSUPPORTED) return rc;
-        BASD_TRY(basd_gemm_tn(a->k_prime, a->a_prime, BASD_DTYPE_F32, 0, n, 1, nn, 0, d_s, 1, (long)n * d_s, 1 << 30, n,
-                              n, d_s, EB, nullptr, nullptr, 1, nullptr, a->h, d_s, (long)n * d_s, 1.f, st));
-        BASD_TRY(basd_student_grad_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, E, B, n_s, n, d_s, a->omega,
-                                         om_stride, a->mu_s, a->h, a->tap0, a->tap1, a->lam, grad_layers,
-                                         2.0f / (float)B, a->dx, nullptr, nullptr, st));
-    }
+    return procrustes_tail(a, grad_layers_in, E, B, n_s, n, d_s, EB, nn, om_stride, st);
 #undef BASD_TRY
-    return BASD_OK;
 }
 
 

@@ -635,6 +635,17 @@ extern "C" {
 
 int basd_jacobi_workspace_ints(int batch, int max_sweeps) { return 2 * batch * max_sweeps; }
 
+// 1 when basd_jacobi_onesided solves a batch (>= 128) of plain n x n matrices in LDS with 4 lanes per column pair
+// (orders 40..144): the transposed Procrustes cores then need no riding rows (basd_procrustes_forward_fused).
+int basd_jacobi_plain4_fits(int n) {
+    const int n_even = (n + 1) & ~1;
+    if (n_even < 40 || n > 144) return 0;
+    static const int p_epl[] = {8, 16, 24, 36};
+    for (int e : p_epl)
+        if (4 * e >= n) return (size_t)n_even * (4 * e + 8 + 2) * sizeof(float) <= BASD_JACOBI_LDS_LIMIT;
+    return 0;
+}
+
 // Test / tuning hook: lanes per column pair of the LDS-resident solver -- 0 = automatic, 4 / 8 / 16 = forced where the
 // shape allows (4 and 8: stacked matrices only).  Process-wide.
 static int g_jacobi_lanes = 0;
@@ -727,6 +738,37 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
                 default: LAUNCH_LDS4(16); break;
             }
 #undef LAUNCH_LDS4
+            BASD_RETURN_LAST();
+        }
+    }
+
+    // ---- LDS-resident, plain square-ish matrices in large batches (the transposed Procrustes cores: no riding rows),
+    // 4 lanes per column pair.  Elements per lane: multiples of 4 (column stride 4 EPL + 8 = 8 x odd). ----
+    if (!stacked && !n_arr && n_even >= 8 && (lanes == 4 || (lanes == 0 && batch >= 128 && n_even >= 40))) {
+        static const int p_epl[] = {8, 16, 24, 36};
+        int e4 = 0;
+        for (int e : p_epl)
+            if (4 * e >= rows_tot) { e4 = e; break; }
+        const size_t lds4 = (size_t)n_even * (4 * e4 + 8 + 2) * sizeof(float);
+        if (e4 && lds4 <= BASD_JACOBI_LDS_LIMIT) {
+            int threads = (((n_even / 2) * 4 + 63) / 64) * 64;
+            if (threads > 1024) threads = 1024;
+#define LAUNCH_P4(E)                                                                                                  \
+    do {                                                                                                              \
+        if (lds4 > 48 * 1024)                                                                                         \
+            (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<E, E, 4>,                                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BASD_JACOBI_LDS_LIMIT);             \
+        jacobi_lds_kernel<E, E, 4><<<batch, threads, lds4, stream>>>(W, batch_stride, rows_dot, rows_tot, n, n_arr,   \
+                                                                     max_sweeps, tol, colnorm, colnorm_stride,        \
+                                                                     sweeps_out);                                     \
+    } while (0)
+            switch (e4) {
+                case 8: LAUNCH_P4(8); break;
+                case 16: LAUNCH_P4(16); break;
+                case 24: LAUNCH_P4(24); break;
+                default: LAUNCH_P4(36); break;
+            }
+#undef LAUNCH_P4
             BASD_RETURN_LAST();
         }
     }

@@ -890,6 +890,120 @@ __global__ void __launch_bounds__(256) stack_product_kernel(const double* __rest
     }
 }
 
+// M = L_a^T L_b alone, row-major and compact (n x n at W + b * w_batch_stride): as a column-major matrix that is M^T, and
+// one-sided Jacobi on M^T leaves V Sigma in its columns (the right singular vectors of M, which is what Y = L_b V
+// needs) -- no riding rows.  grid = (ceil(n/32), ceil(n/32), batch), block = 256.
+__global__ void __launch_bounds__(256) stack_product_t_kernel(const double* __restrict__ La, const double* __restrict__ Lb,
+                                                              long l_batch_stride, int n, float* __restrict__ W,
+                                                              long w_batch_stride, int lb_period) {
+    __shared__ double ta[32][33], tb[32][33];     // [k][i], [k][j]
+    const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32, tid = threadIdx.x;
+    const double* A = La + (long)b * l_batch_stride;
+    const double* B = Lb + (long)(b % lb_period) * l_batch_stride;
+    const int tx = tid & 31, ty = tid >> 5;       // tx: j within the tile, ty + 8 r: i within the tile
+    double acc[4] = {0., 0., 0., 0.};
+    for (int k0 = i0 > j0 ? i0 : j0; k0 < n; k0 += 32) {
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int kk = idx >> 5, c = idx & 31, k = k0 + kk;
+            ta[kk][c] = (k < n && i0 + c < n) ? A[(long)k * n + i0 + c] : 0.;
+            tb[kk][c] = (k < n && j0 + c < n) ? B[(long)k * n + j0 + c] : 0.;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const double bv = tb[kk][tx];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fma(ta[kk][ty + 8 * r], bv, acc[r]);
+        }
+    }
+    float* Wb = W + (long)b * w_batch_stride;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + ty + 8 * r, j = j0 + tx;
+        if (i < n && j < n) Wb[(long)i * n + j] = (float)acc[r];
+    }
+}
+
+// After the Jacobi on M^T (columns c of X = V_c sigma_c, compact n x n at W + b * w_batch_stride):
+//   Z[c][a] = sigma_c^-1.5 sum_{r <= a} L_b[a][r] X[r][c]  = (L_b V)[a][c] sigma_c^-1/2      (0 for truncated sigma)
+//   K'[a][b] = sum_c Z[c][a] Z[c][b]                          = Y Sigma^+ Y^T
+// 32 x 32 tiles; Z goes to z (batch stride z_batch_stride).  grid = (ceil(n/32), ceil(n/32), batch), block = 256.
+__global__ void __launch_bounds__(256) kprime_z_kernel(const float* __restrict__ W, long w_batch_stride,
+                                                       const float* __restrict__ sigma, int n,
+                                                       const double* __restrict__ Lb, long l_batch_stride, int lb_period,
+                                                       float* __restrict__ Z, long z_batch_stride) {
+    __shared__ float lt[32][33], wt[32][33];      // lt[a][r], wt[c][r]
+    __shared__ float red[4];
+    const int b = blockIdx.z, a0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tid = threadIdx.x;
+    const float* sg = sigma + (long)b * n;
+    float smax = 0.f;
+    for (int j = tid; j < n; j += 256) smax = fmaxf(smax, sg[j]);
+    smax = wave_max(smax);
+    if ((tid & 63) == 0) red[tid >> 6] = smax;
+    __syncthreads();
+    smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float thr = smax * (float)n * 1.1920929e-7f;
+    const float* Wb = W + (long)b * w_batch_stride;
+    const double* L = Lb + (long)(b % lb_period) * l_batch_stride;
+    const int tx = tid & 31, ty = tid >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < a0 + 32 && r0 < n; r0 += 32) {
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int i = idx >> 5, rr = idx & 31, r = r0 + rr;
+            lt[i][rr] = (a0 + i < n && r <= a0 + i) ? (float)L[(long)(a0 + i) * n + r] : 0.f;
+            wt[i][rr] = (c0 + i < n && r < n) ? Wb[(long)(c0 + i) * n + r] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) {
+            const float lv = lt[tx][rr];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(lv, wt[ty + 8 * i][rr], acc[i]);
+        }
+    }
+    float* Zb = Z + (long)b * z_batch_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, a = a0 + tx;
+        if (c < n && a < n) {
+            const float sv = sg[c];
+            Zb[(long)c * n + a] = acc[i] * (sv > thr ? 1.f / (sv * sqrtf(sv)) : 0.f);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) kprime_from_z_kernel(const float* __restrict__ Z, long z_batch_stride, int n,
+                                                            float* __restrict__ Kp) {
+    __shared__ float za[32][33], zb[32][33];      // [c][a], [c][b]
+    const int b = blockIdx.z, a0 = blockIdx.y * 32, b0 = blockIdx.x * 32, tid = threadIdx.x;
+    const float* Zb = Z + (long)b * z_batch_stride;
+    const int tx = tid & 31, ty = tid >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < n; c0 += 32) {
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int cc = idx >> 5, i = idx & 31, c = c0 + cc;
+            za[cc][i] = (c < n && a0 + i < n) ? Zb[(long)c * n + a0 + i] : 0.f;
+            zb[cc][i] = (c < n && b0 + i < n) ? Zb[(long)c * n + b0 + i] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int cc = 0; cc < 32; ++cc) {
+            const float bv = zb[cc][tx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fmaf(za[cc][ty + 8 * i], bv, acc[i]);
+        }
+    }
+    float* K = Kp + (long)b * n * n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int a = a0 + ty + 8 * i, bb = b0 + tx;
+        if (a < n && bb < n) K[(long)a * n + bb] = acc[i];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Finalize: nuclear norm, teacher trace, per-sample loss, and K' = Y Sigma^+ Y^T.
 // grid = batch, block = 256.  W is the rotated stack (top: U Sigma, bottom: Y = L_b V).
@@ -1371,6 +1485,29 @@ int basd_stack_product(const double* la, const double* lb, long l_batch_stride, 
         const int nt = (n + 31) / 32;
         stack_product_global_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride, lb_period);
     }
+    BASD_RETURN_LAST();
+}
+
+// The stacked product without the stack: M = L_a^T L_b row-major and compact at w + b * w_batch_stride (= M^T as a
+// column-major matrix: the one-sided Jacobi on it leaves V Sigma, see basd_kprime_from_transposed).
+int basd_stack_product_t(const double* la, const double* lb, long l_batch_stride, int n, int batch, int lb_period,
+                         float* w, long w_batch_stride, hipStream_t stream) {
+    BASD_CHECK_ARG(la && lb && w && n > 0 && batch > 0 && lb_period > 0 && batch <= 65535);
+    const int nt = (n + 31) / 32;
+    stack_product_t_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(la, lb, l_batch_stride, n, w, w_batch_stride, lb_period);
+    BASD_RETURN_LAST();
+}
+
+// K' = Y Sigma^+ Y^T from the rotated TRANSPOSED core (columns V_c sigma_c, compact n x n at w + b * w_batch_stride),
+// sigma and the teacher-side factor L_b: Y = L_b V is formed here instead of riding through the rotations.
+// z: scratch, n x n floats per matrix at z + b * z_batch_stride.
+int basd_kprime_from_transposed(const float* w, long w_batch_stride, const float* sigma, int n, int batch,
+                                const double* lb, long l_batch_stride, int lb_period, float* z, long z_batch_stride,
+                                float* k_prime, hipStream_t stream) {
+    BASD_CHECK_ARG(w && sigma && lb && z && k_prime && n > 0 && batch > 0 && lb_period > 0 && batch <= 65535);
+    const int nt = (n + 31) / 32;
+    kprime_z_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(w, w_batch_stride, sigma, n, lb, l_batch_stride, lb_period, z, z_batch_stride);
+    kprime_from_z_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(z, z_batch_stride, n, k_prime);
     BASD_RETURN_LAST();
 }
 
