@@ -742,6 +742,23 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
         }
     }
 
+    // ---- the same with 8 lanes per pair for long columns at about one matrix per CU (cfg-5: 256 cores of 144 x 144):
+    // what counts there is the latency of one round, and half the elements per lane shorten it ----
+    if (!stacked && !n_arr && rows_tot > 96 && rows_tot <= 160 && n_even <= 160 &&
+        (lanes == 8 || (lanes == 0 && batch >= 128 && batch <= 320))) {
+        const size_t lds8p = (size_t)n_even * (8 * 20 + 16 + 2) * sizeof(float);
+        if (lds8p <= BASD_JACOBI_LDS_LIMIT) {
+            int threads = (((n_even / 2) * 8 + 63) / 64) * 64;
+            if (threads > 1024) threads = 1024;
+            (void)hipFuncSetAttribute((const void*)jacobi_lds_kernel<20, 20, 8>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BASD_JACOBI_LDS_LIMIT);
+            jacobi_lds_kernel<20, 20, 8><<<batch, threads, lds8p, stream>>>(W, batch_stride, rows_dot, rows_tot, n, n_arr,
+                                                                            max_sweeps, tol, colnorm, colnorm_stride,
+                                                                            sweeps_out);
+            BASD_RETURN_LAST();
+        }
+    }
+
     // ---- LDS-resident, plain square-ish matrices in large batches (the transposed Procrustes cores: no riding rows),
     // 4 lanes per column pair.  Elements per lane: multiples of 4 (column stride 4 EPL + 8 = 8 x odd). ----
     if (!stacked && !n_arr && n_even >= 8 && (lanes == 4 || (lanes == 0 && batch >= 128 && n_even >= 40))) {
