@@ -11,7 +11,8 @@
  *     (pass torch.cuda.current_stream().cuda_stream); scratch buffers are caller-provided;
  *   - return value: 0 = ok, <0 = invalid argument / unsupported shape (BASD_E*), >0 = hipError_t;
  *   - dtype codes: 0 = fp32, 1 = bf16 (inputs only; all arithmetic and outputs are fp32/fp64);
- *   - entry points are re-entrant and keep no global mutable state (one exception, for tests: basd_tridiag_tuning).
+ *   - entry points are re-entrant and keep no global mutable state, with three process-wide test / tuning hooks as the
+ *     only exceptions: basd_tridiag_tuning, basd_jacobi_tuning, basd_procrustes_tuning (none is called by the loss).
  */
 #ifndef BASD_HIP_H
 #define BASD_HIP_H
@@ -222,6 +223,63 @@ int basd_selector_tail(const float* t_d, const float* t_e, const float* t_tau, c
                        float* v_s, float* z_t, float* u_t, float* u_rot, float* sw, float* cos, int* k_arr,
                        const int* sw_index, float* sigma, int* flags, float* d_out, hipStream_t stream);
 
+/* The selector of one loss step queued by ONE call over three streams (layer_selector.py:69-74 `_estimate_ranks`,
+ * :131-138 teacher subspaces, :86-105 `_mix_for_student_layer` up to d_grass_sq): teacher projections z_l =
+ * tokens_l proj_t^T, uncentred / M and centred Grams of every z_l, centred Grams of the E student layers, the
+ * Householder tridiagonalisation of all 2L + E matrices with the Marchenko-Pastur ranks of the L uncentred ones
+ * written to `ranks` (device) and `host_mirror` (pinned host: L ranks + the 8 status words of basd_tridiag_ranked)
+ * by the kernel that finishes the factorisation, then -- on tail_stream, with the ranks taken from DEVICE memory --
+ * what basd_selector_tail does.  The host only waits for ev_ranks (basd_event_synchronize) to refresh
+ * `subspace_ranks` and to raise on rank 0 like the reference.
+ *   kmax: eigenvectors computed per matrix in the tail, a HINT (the previous step's largest rank); any value >= the
+ *         largest rank of this step gives the same d_grass_sq; if the ranks read back exceed it, call
+ *         basd_selector_chain_tail(args, larger kmax) again.  0: do not queue the tail (first step: no hint yet).
+ *   mode: 0 = one factorisation launch over all 2L + E matrices (student Grams formed on student_stream beside the
+ *             teacher's projections);
+ *         1 = teacher matrices first; the student side (Grams + factorisation, student_stream != chain_stream) is
+ *             held back until the ranks are out;   2 = the same, not held back.
+ *   streams: main_stream = the caller's (inputs are ready there); events are opaque handles of basd_event_create:
+ *         ev_fork / ev_student / ev_ranks / ev_tail are recorded by the call; ev_slot_free (nullable) is waited for
+ *         before anything is written: the ev_tail of the call that used these buffers last.
+ *   Every field is 8 bytes wide.  Device buffers (floats unless noted), n = d_s, M_t = B n_t, nt = ceil(M_t / 128):
+ *         z (L, M_t, n); z_sums (L, nt, n); z_ptrs: device table of 2L pointers [z_0..z_{L-1}, z_0..z_{L-1}];
+ *         t_scales (2L): 1/M_t x L then 1 x L; t_slabs (2L t_splits n n), t_splits = basd_syrk_splits(M_t, n, 2L);
+ *         s_partial (E s_parts n), s_parts = basd_colmean_parts(B n_s); s_means (E, n); s_slabs (E s_splits n n);
+ *         grams, vh (2L + E, n, n); d, e, tau, vals (2L + E, n); tri_work: basd_tridiag_workspace_bytes(n, 2L + E)
+ *         bytes (modes 1, 2: (n, 2L) and tri_work_s (n, E)); ranks (L ints);
+ *         tail, K = kmax_cap >= kmax: zv, vecs ((L + E) K n); u_rot (L K n); sw (L K); cos (E L K K); sigma (E L K);
+ *         d_out (E L); k_arr (E L ints); sw_index (E L ints, item e L + l -> l);
+ *         jflags (basd_jacobi_workspace_ints(E L, 20) ints).
+ * Returns BASD_EUNSUPPORTED when B n_t < d_s (the reference then forms the token-side Gram, layer_selector.py:14-15):
+ * take the per-kernel entry points. */
+typedef struct BasdSelectorChain {
+    const void* const* teacher_host_ptrs;  /* HOST array of L device pointers: (B, n_t, d_t) views with common strides */
+    long t_dtype, t_sb, t_sn, t_sd;
+    const void* const* student_ptrs;       /* device table of E pointers: (B, n_s, d_s) views with common strides */
+    long s_dtype, s_sb, s_sn, s_sd, s_vec_ok;
+    const float* proj_t;                   /* (d_s, d_t) fp32 row-major */
+    const float* proj_s_t;                 /* (d_s, d_s) fp32: proj_s^T */
+    long E, L, B, n_s, n_t, d_s, d_t;
+    double mp_factor;                      /* (1 + sqrt(d_s / M_t))^2, float64 on the host as layer_selector.py:11,18 */
+    long rank_cap;                         /* d_s - 1 (layer_selector.py:74) */
+    long kmax, kmax_cap, mode;
+    float* z; float* z_sums; const void* const* z_ptrs; const float* t_scales; float* t_slabs; long t_splits;
+    float* s_partial; float* s_means; float* s_slabs; long s_splits, s_parts;
+    float* grams; float* d; float* e; float* tau; float* vh; float* vals; void* tri_work; void* tri_work_s;
+    int* ranks; int* host_mirror;          /* host_mirror: pinned host memory, L + 8 ints (nullable) */
+    int* student_status_mirror;            /* modes 1, 2: pinned host memory, 8 ints (nullable) */
+    float* zv; float* vecs; float* u_rot; float* sw; float* cos; float* sigma; float* d_out;
+    int* k_arr; const int* sw_index; int* jflags;
+    hipStream_t main_stream, chain_stream, student_stream, tail_stream;
+    void* ev_fork; void* ev_student; void* ev_ranks; void* ev_tail; void* ev_slot_free;
+} BasdSelectorChain;
+int basd_selector_chain(const BasdSelectorChain* args);
+/* exact_k != 0: the caller has READ the ranks and every one of them equals kmax (one teacher layer): the principal-angle
+ * matrices then have one common order and may leave LDS (orders past basd_jacobi_lds_square_fits; a speculative kmax
+ * past it returns BASD_EUNSUPPORTED). */
+int basd_selector_chain_tail(const BasdSelectorChain* args, int kmax, int exact_k);
+int basd_jacobi_lds_square_fits(int n);
+
 /* ---- attention-weighted Procrustes loss ------------------------------------------------------ */
 
 /* Token weights from the layer-mixed attention.  relational.py:22-34 + layer_selector.py:112.
@@ -393,6 +451,9 @@ int basd_cross_entropy(const void* logits, int dtype, long ld, int B, int C, con
 int basd_event_create(void** out);
 int basd_event_destroy(void* event);
 int basd_stream_wait_event(hipStream_t stream, void* event);
+int basd_event_record(void* event, hipStream_t stream);
+int basd_event_synchronize(void* event);      /* blocks the calling host thread */
+int basd_event_query(void* event);            /* 1 = reached, 0 = not yet, < 0 = invalid */
 
 /* ---- multi-layer teachers only: gradients through the mixing weights and the principal angles ------ */
 

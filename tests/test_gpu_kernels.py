@@ -379,6 +379,106 @@ def test_tridiag_mp_rank_matches_full_spectrum(dev, n, M):
     assert pin.tolist() == ref[:2].tolist() + [0] * 8
 
 
+def _ulp_step(x: np.float32, steps: int) -> np.float32:
+    x = np.float32(x)
+    for _ in range(abs(steps)):
+        x = np.nextafter(x, np.float32(np.inf if steps > 0 else -np.inf), dtype=np.float32)
+    return x
+
+
+@pytest.mark.parametrize("n,M", [(384, 12544), (100, 300)])
+def test_mp_rank_near_the_threshold(dev, n, M):
+    """Tie policy of the Marchenko-Pastur rank (layer_selector.py:16-19: lower median, float64 factor, threshold rounded
+    to fp32, STRICT ``>``), DESIGN.md section 2.  Diagonal Grams make every eigenvalue exact in every route, so the
+    comparison is decidable to the last bit: one eigenvalue is planted 0, +-1, +-4, +-64 ulps from
+    fp32(median * factor).
+      * from a given spectrum (``basd_mp_rank``, what ``marchenko_pastur_rank`` / ``_estimate_ranks`` end in): exact at
+        every offset, equality is NOT counted;
+      * straight from the tridiagonal (``basd_tridiag_ranked`` / ``basd_tridiag_mp_rank``, the training step): the
+        median comes out of a bisection that stops at a 2-ulp bracket, so the threshold itself is only known to
+        +-2 ulps: exact from 4 ulps on, within the two neighbouring answers below that."""
+    from basd_amd import ops
+    rng = np.random.default_rng(n)
+    factor = (1 + (n / M) ** 0.5) ** 2
+    k_sig = 7
+    # the bulk stays below the threshold (median ~0.8, factor >= 1.38): only the planted eigenvalue sits next to it
+    bulk = rng.uniform(0.6, 1.0, n - k_sig - 1).astype(np.float32)
+    signal = rng.uniform(20.0, 60.0, k_sig).astype(np.float32)
+    for off in (0, 1, -1, 4, -4, 64, -64):
+        base = np.concatenate([bulk, signal])
+        # the planted value replaces nothing below the median: it is far above it for every offset
+        med = np.sort(np.concatenate([base, [np.float32(10.0)]]))[(n - 1) // 2]
+        thr = np.float32(np.float64(med) * factor)
+        planted = _ulp_step(thr, off)
+        lam = np.concatenate([base, [planted]]).astype(np.float32)
+        assert np.sort(lam)[(n - 1) // 2] == med
+        expect = int((lam > thr).sum())
+        with_planted, without = k_sig + 1, k_sig
+        assert expect == (with_planted if off > 0 else without)        # equality (off == 0) is NOT counted
+        perm = rng.permutation(n)
+        diag = torch.from_numpy(lam[perm])
+        # (1) from the spectrum
+        vals = torch.from_numpy(np.sort(lam)[::-1].copy()).to(dev).unsqueeze(0)
+        assert int(ops.mp_rank_device(vals, M, n, cap=n - 1)[0]) == expect, off
+        # (2) straight from the tridiagonal, both entry points
+        G = torch.diag(diag).to(dev).unsqueeze(0).contiguous()
+        pin = torch.empty((1 + 8,), dtype=torch.int32, pin_memory=True)
+        ts = ops.tridiagonalise(G.clone(), mp_rank=(M, n, n - 1, 1, pin))
+        ops.tridiag_spectrum(ts)
+        alone = ops.tridiag_mp_rank(ts, M, n, cap=n - 1)
+        torch.cuda.synchronize()
+        for got in (int(ts.ranks[0]), int(alone[0]), int(pin[0])):
+            if abs(off) >= 4:
+                assert got == expect, (off, got, expect)
+            else:
+                assert got in (with_planted, without), (off, got)
+        # the bisection spectrum of a diagonal matrix is the diagonal itself
+        assert np.array_equal(ts.vals[0].cpu().numpy(), np.sort(lam)[::-1])
+
+
+def test_mp_rank_dense_with_a_planted_gap(dev):
+    """The same question for dense Grams, where it is only decidable up to the accuracy of ANY fp32 symmetric
+    eigen-solver (the reference's LAPACK route included): ~n eps lambda_max.  An eigenvalue planted 2e-3 (relative)
+    above / below the threshold must be counted / not counted, as the fp64 spectrum of the same fp32 matrix says."""
+    from basd_amd import ops
+    n, M = 384, 12544
+    g = torch.Generator().manual_seed(5)
+    q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+    factor = (1 + (n / M) ** 0.5) ** 2
+    rng = np.random.default_rng(5)
+    for rel in (2e-3, -2e-3):
+        lam = np.concatenate([rng.uniform(0.6, 1.0, n - 9), rng.uniform(8.0, 14.0, 8)])
+        med = np.sort(np.concatenate([lam, [10.0]]))[(n - 1) // 2]
+        lam = np.concatenate([lam, [med * factor * (1 + rel)]])
+        G = (q @ torch.diag(torch.from_numpy(lam)) @ q.T)
+        G = ((G + G.T) / 2).float()
+        ev = torch.linalg.eigvalsh(G.double())
+        thr = float(np.float32(float(ev[(n - 1) // 2]) * factor))
+        ref = int((ev > thr).sum())
+        assert ref == (9 if rel > 0 else 8)
+        pin = torch.empty((1 + 8,), dtype=torch.int32, pin_memory=True)
+        ts = ops.tridiagonalise(G.to(dev).unsqueeze(0).contiguous(), mp_rank=(M, n, n - 1, 1, pin))
+        torch.cuda.synchronize()
+        assert int(ts.ranks[0]) == ref and int(pin[0]) == ref, (rel, int(ts.ranks[0]), ref)
+
+
+def test_align_token_count_golden(dev, golden):
+    """``_align_token_count`` (combined.py:9-14) against the reference's own outputs (tests/golden/align.npz, written by
+    the imported reference): 49 -> 196, 256 -> 196, 144 -> 576, 1 -> 64, identity, and a down-sampling case."""
+    from basd_amd.losses import _align_token_count
+    g = golden("align.npz")
+    for tag in ("49_196", "256_196", "144_576", "1_64", "64_64", "7_3"):
+        x = torch.from_numpy(g[f"{tag}_x"]).to(dev)
+        want = g[f"{tag}_y"]
+        y = _align_token_count(x, want.shape[1])
+        np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-6, atol=1e-7, err_msg=tag)
+        # strided input (a CLS-sliced view), as the trainer hands it over
+        full = torch.zeros(x.shape[0], x.shape[1] + 1, x.shape[2], device=dev)
+        full[:, 1:] = x
+        np.testing.assert_allclose(_align_token_count(full[:, 1:], want.shape[1]).cpu().numpy(), want, rtol=2e-6,
+                                   atol=1e-7, err_msg=tag + " strided")
+
+
 @pytest.mark.parametrize("n", [384, 100, 45])
 def test_tridiag_apply_q_and_shifted_solve(dev, n):
     """The reflector product in both directions and the shifted tridiagonal solve behind the multi-layer backward."""
@@ -469,6 +569,36 @@ def test_fused_cross_entropy_matches_torch(dev, soft, eps, dtype):
     (lb * 1.7).backward()
     ref = b.grad
     assert ((a.grad.float() - ref).abs().max() / ref.abs().max()).item() < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+def test_fused_cross_entropy_edge_cases(dev):
+    """What nn.CrossEntropyLoss does at the edges: soft targets that do not sum to 1 (no normalisation is assumed),
+    every row ignored (0 / 0 = NaN), and a class index outside [0, C) (torch device-asserts; here the loss is NaN and
+    nothing is read out of bounds)."""
+    from basd_amd import losses
+    g = torch.Generator().manual_seed(4)
+    B, C = 9, 50
+    logits = torch.randn(B, C, generator=g).to(dev)
+    for eps in (0.0, 0.1):
+        crit = torch.nn.CrossEntropyLoss(label_smoothing=eps)
+        soft = (torch.rand(B, C, generator=g) * 0.1).to(dev)            # row sums ~2.5, all different
+        a = logits.clone().requires_grad_(True)
+        b = logits.clone().requires_grad_(True)
+        la, lb = losses._base_loss(crit, a, soft), crit(b, soft)
+        assert type(la.grad_fn).__name__.startswith("_FusedCrossEntropy")
+        assert abs(la.item() - lb.item()) <= 1e-5 * abs(lb.item())
+        la.backward()
+        lb.backward()
+        assert ((a.grad - b.grad).abs().max() / b.grad.abs().max()).item() < 1e-5
+        ignored = torch.full((B,), -100, dtype=torch.int64, device=dev)
+        assert math.isnan(losses._base_loss(crit, logits, ignored).item()) and math.isnan(crit(logits, ignored).item())
+        bad = torch.randint(0, C, (B,), generator=g).to(dev)
+        bad[3] = C + 5
+        a = logits.clone().requires_grad_(True)
+        out = losses._base_loss(crit, a, bad)
+        assert math.isnan(out.item())
+        out.backward()
+        assert not a.grad[3].any()
 
 
 @pytest.mark.parametrize("side_s, side_t, d_s, E, B, dtype", [

@@ -87,6 +87,12 @@ SIGNATURES = {
     "basd_build_angle_stack": [vp, i32, vp, i32, vp, vp],
     "basd_grassmann_distance_bwd": [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp],
     "basd_eigvec_k2": [vp, vp, i32, i32, i32, vp, vp],
+    "basd_selector_chain": [vp],
+    "basd_selector_chain_tail": [vp, i32, i32],
+    "basd_jacobi_lds_square_fits": [i32],
+    "basd_event_record": [vp, vp],
+    "basd_event_synchronize": [vp],
+    "basd_event_query": [vp],
 }
 
 class ProcrustesArgs(C.Structure):
@@ -106,6 +112,24 @@ class ProcrustesArgs(C.Structure):
                              "grad_layers", "g_slabs")]
         + [("g_splits", i64)]
         + [("uw_ce", vp), ("uw_out", vp), ("jac_ws", vp)]
+    )
+
+
+class SelectorChainArgs(C.Structure):
+    """BasdSelectorChain of include/basd_hip.h (every field 8 bytes wide)."""
+    _fields_ = (
+        [("teacher_host_ptrs", vp)] + [(n, i64) for n in ("t_dtype", "t_sb", "t_sn", "t_sd")]
+        + [("student_ptrs", vp)] + [(n, i64) for n in ("s_dtype", "s_sb", "s_sn", "s_sd", "s_vec_ok")]
+        + [("proj_t", vp), ("proj_s_t", vp)]
+        + [(n, i64) for n in ("E", "L", "B", "n_s", "n_t", "d_s", "d_t")]
+        + [("mp_factor", f64)]
+        + [(n, i64) for n in ("rank_cap", "kmax", "kmax_cap", "mode")]
+        + [(n, vp) for n in ("z", "z_sums", "z_ptrs", "t_scales", "t_slabs")] + [("t_splits", i64)]
+        + [(n, vp) for n in ("s_partial", "s_means", "s_slabs")] + [("s_splits", i64), ("s_parts", i64)]
+        + [(n, vp) for n in ("grams", "d", "e", "tau", "vh", "vals", "tri_work", "tri_work_s", "ranks", "host_mirror",
+                             "student_status_mirror", "zv", "vecs", "u_rot", "sw", "cos", "sigma", "d_out", "k_arr",
+                             "sw_index", "jflags", "main_stream", "chain_stream", "student_stream", "tail_stream",
+                             "ev_fork", "ev_student", "ev_ranks", "ev_tail", "ev_slot_free")]
     )
 
 

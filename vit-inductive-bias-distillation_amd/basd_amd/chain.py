@@ -1,0 +1,162 @@
+"""Host side of ``basd_selector_chain`` (csrc/chain.hip): the selector of one loss step -- ranks
+(layer_selector.py:69-74), teacher subspaces (:131-138), principal angles and d_grass_sq (:86-105) -- queued by ONE
+library call into a persistent, shape-keyed workspace.
+
+A plan owns two slots of device buffers (the tail of step i may still read its factorisation while step i + 1 writes
+the next one), the events that order the three streams, the pinned host words the rank kernel writes, and one
+pre-filled argument block per slot; a step only patches the input pointers.  No ``torch.empty``, no Python event
+objects and a single FFI call on the path in front of the chain the host waits for.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+
+SPEC_MARGIN = 8            # eigenvectors computed beyond the previous step's largest rank (the rank may grow a little)
+
+
+def _event() -> int:
+    h = C.c_void_p()
+    _lib.call("basd_event_create", C.byref(h))
+    return h.value
+
+
+class _Slot:
+    """One set of device buffers + events + the argument block that points at them."""
+
+    def __init__(self, plan: "SelectorChainPlan"):
+        p = plan
+        dev, f32, i32 = p.device, torch.float32, torch.int32
+        E, L, n, K = p.E, p.L, p.d_s, p.kmax_cap
+        M_t, M_s = p.B * p.n_t, p.B * p.n_s
+        tiles = (M_t + 127) // 128
+        nmat = 2 * L + E
+
+        def buf(count, dtype=f32):
+            return torch.empty((int(count),), device=dev, dtype=dtype)
+
+        self.t_splits = _lib.query("basd_syrk_splits", M_t, n, 2 * L)
+        self.s_splits = _lib.query("basd_syrk_splits", M_s, n, E)
+        self.s_parts = _lib.query("basd_colmean_parts", M_s)
+        b = self.bufs = dict(
+            z=buf(L * M_t * n), z_sums=buf(L * tiles * n), t_slabs=buf(2 * L * self.t_splits * n * n),
+            s_partial=buf(E * self.s_parts * n), s_means=buf(E * n), s_slabs=buf(E * self.s_splits * n * n),
+            grams=buf(nmat * n * n), d=buf(nmat * n), e=buf(nmat * n), tau=buf(nmat * n), vh=buf(nmat * n * n),
+            vals=buf(nmat * n), ranks=buf(L, i32),
+            zv=buf((L + E) * K * n), vecs=buf((L + E) * K * n), u_rot=buf(L * K * n), sw=buf(L * K),
+            cos=buf(E * L * K * K), sigma=buf(E * L * K), k_arr=buf(E * L, i32),
+            jflags=buf(_lib.query("basd_jacobi_workspace_ints", E * L, ops.MAX_SWEEPS), i32),
+        )
+        split = p.mode != 0
+        b["tri_work"] = buf(_lib.query("basd_tridiag_workspace_bytes", n, 2 * L if split else nmat), torch.uint8)
+        b["tri_work_s"] = buf(_lib.query("basd_tridiag_workspace_bytes", n, E), torch.uint8) if split else None
+        b["z_ptrs"] = torch.tensor([b["z"].data_ptr() + 4 * l * M_t * n for l in range(L)] * 2, dtype=torch.int64).to(dev)
+        b["t_scales"] = torch.tensor([1.0 / M_t] * L + [1.0] * L, dtype=f32).to(dev)
+        b["sw_index"] = torch.tensor(list(range(L)) * E, dtype=i32).to(dev)
+        self.mirror = torch.zeros((L + 8,), dtype=i32).pin_memory()
+        self.student_mirror = torch.zeros((8,), dtype=i32).pin_memory() if split else None
+        self.ev_fork, self.ev_student, self.ev_ranks, self.ev_tail = (_event() for _ in range(4))
+        self.used = False                   # ev_tail has been recorded at least once
+        self.student_status_pending = False
+        self.teacher_ptrs = (C.c_void_p * L)()
+        self.d_out = None                   # this step's (E, L) output tensor (fresh per step)
+
+        a = self.args = _lib.SelectorChainArgs()
+        a.teacher_host_ptrs = C.cast(self.teacher_ptrs, C.c_void_p)
+        a.E, a.L, a.B, a.n_s, a.n_t, a.d_s, a.d_t = E, L, p.B, p.n_s, p.n_t, n, p.d_t
+        a.mp_factor = (1 + (n / M_t) ** 0.5) ** 2          # float64 on the host, as layer_selector.py:11,18
+        a.rank_cap, a.kmax_cap, a.mode = n - 1, K, p.mode
+        a.t_splits, a.s_splits, a.s_parts = self.t_splits, self.s_splits, self.s_parts
+        for name in ("z", "z_sums", "z_ptrs", "t_scales", "t_slabs", "s_partial", "s_means", "s_slabs", "grams", "d", "e",
+                     "tau", "vh", "vals", "tri_work", "tri_work_s", "ranks", "zv", "vecs", "u_rot", "sw", "cos", "sigma",
+                     "k_arr", "sw_index", "jflags"):
+            setattr(a, name, None if b[name] is None else b[name].data_ptr())
+        a.host_mirror = self.mirror.data_ptr()
+        a.student_status_mirror = None if self.student_mirror is None else self.student_mirror.data_ptr()
+        a.ev_fork, a.ev_student, a.ev_ranks, a.ev_tail = self.ev_fork, self.ev_student, self.ev_ranks, self.ev_tail
+
+
+class SelectorChainPlan:
+    """Persistent workspace + argument blocks of ``basd_selector_chain`` for one (shapes, layouts, device) key."""
+
+    @staticmethod
+    def key(students, teachers, mode: int):
+        s, t = students[0], teachers[0]
+        return (len(students), len(teachers), tuple(s.shape), s.stride(), s.dtype, tuple(t.shape), t.stride(), t.dtype,
+                str(s.device), mode)
+
+    @staticmethod
+    def supported(students, teachers) -> bool:
+        s, t = students[0], teachers[0]
+        if ops.EIG_SOLVER != "tridiag" or s.dim() != 3 or t.dim() != 3:
+            return False
+        B, n_t, _ = t.shape
+        return B * n_t >= s.shape[2] and s.shape[2] >= 2 and s.shape[2] <= 1024
+
+    def __init__(self, students, teachers, mode: int, streams):
+        s, t = students[0], teachers[0]
+        self.E, self.L = len(students), len(teachers)
+        self.B, self.n_s, self.d_s = s.shape
+        _, self.n_t, self.d_t = t.shape
+        self.device, self.mode = s.device, mode
+        self.kmax_cap = self.d_s - 1
+        self.chain_stream, self.student_stream, self.tail_stream = streams
+        self.slots = [_Slot(self), _Slot(self)]
+        self.turn = 0
+        self.hint = 0                      # previous step's largest rank (0: none yet)
+        for slot in self.slots:
+            a = slot.args
+            a.t_dtype, (a.t_sb, a.t_sn, a.t_sd) = ops._dtype_code(t), t.stride()
+            a.s_dtype, (a.s_sb, a.s_sn, a.s_sd) = ops._dtype_code(s), s.stride()
+            a.chain_stream = self.chain_stream.cuda_stream
+            a.student_stream = self.student_stream.cuda_stream
+            a.tail_stream = self.tail_stream.cuda_stream
+
+    def speculative_kmax(self) -> int:
+        """Eigenvectors the tail computes before the host has seen this step's ranks (0: wait for them)."""
+        if self.hint <= 0:
+            return 0
+        k = min(self.hint + SPEC_MARGIN, self.kmax_cap)
+        return k if _lib.query("basd_jacobi_lds_square_fits", k) else 0
+
+    def queue(self, students, teachers, proj_t: torch.Tensor, proj_s_t: torch.Tensor, main_stream: int) -> _Slot:
+        """Queue the whole selector of this step; returns the slot whose ``ev_ranks`` / ``mirror`` the host reads."""
+        slot = self.slots[self.turn]
+        self.turn ^= 1
+        a = slot.args
+        for l, t in enumerate(teachers):
+            slot.teacher_ptrs[l] = t.data_ptr()
+        a.student_ptrs = ops._ptr_table(students).data_ptr()
+        a.s_vec_ok = int(all(x.data_ptr() % 16 == 0 for x in students))
+        a.proj_t, a.proj_s_t = proj_t.data_ptr(), proj_s_t.data_ptr()
+        a.main_stream = main_stream
+        a.ev_slot_free = slot.ev_tail if slot.used else None
+        slot.d_out = torch.empty((self.E, self.L), device=self.device, dtype=torch.float32)
+        slot.d_out.record_stream(self.tail_stream)
+        a.d_out = slot.d_out.data_ptr()
+        slot.kmax = a.kmax = self.speculative_kmax()
+        _lib.call("basd_selector_chain", C.addressof(a))
+        slot.used = slot.used or slot.kmax > 0
+        slot.student_status_pending = self.mode != 0
+        return slot
+
+    def read_ranks(self, slot: _Slot) -> tuple[list[int], list[int]]:
+        """Block on the rank kernel of ``slot`` (nothing else); returns (ranks, the factorisation's 8 status words)."""
+        _lib.call("basd_event_synchronize", slot.ev_ranks)
+        host = slot.mirror.tolist()
+        return host[:self.L], host[self.L:]
+
+    def finish_tail(self, slot: _Slot, ranks: list[int]) -> torch.Tensor:
+        """Make sure the tail of ``slot`` has been queued with enough eigenvectors for ``ranks``; returns d_grass_sq
+        (E, L), written on the tail stream."""
+        need = max(ranks)
+        if need > slot.kmax:
+            exact = self.L == 1
+            kmax = need if exact else min(max(need, self.hint) + SPEC_MARGIN, self.kmax_cap)
+            _lib.call("basd_selector_chain_tail", C.addressof(slot.args), kmax, int(exact))
+            slot.kmax, slot.used = kmax, True
+        self.hint = need
+        return slot.d_out

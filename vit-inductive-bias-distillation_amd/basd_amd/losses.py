@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .chain import SelectorChainPlan
 
 __all__ = [
     "BASDLoss", "GrassmannianLayerSelector", "geometric_relational_loss", "marchenko_pastur_rank",
@@ -844,6 +845,7 @@ class GrassmannianLayerSelector(nn.Module):
                        teachers: list[torch.Tensor]) -> torch.Tensor:
         """softmax(-d / tau) per extraction layer -> (E, L)   (layer_selector.py:107-108)."""
         d = self._distances(students, keys, teachers)
+        self._last_d_grass_sq = d.detach()                  # layer_selector.py:105, kept for ``last_components``
         tau = self.temperatures.float()
         return torch.softmax(-d / tau.unsqueeze(1), dim=1)
 
@@ -953,6 +955,11 @@ class BASDLoss(nn.Module):
         # (or ``sync_ranks = False``): with one teacher layer the ranks do not feed the loss, the read-back is then
         # completed by the next forward / the first reader of ``subspace_ranks`` and consecutive steps may overlap.
         self.sync_ranks = os.environ.get("BASD_RANK_READBACK", "sync") != "deferred"
+        # single-teacher steps: the selector as ONE library call into a persistent workspace (basd_selector_chain);
+        # BASD_SELECTOR_CHAIN=0 keeps the kernel-by-kernel layout.  chain_mode: see BasdSelectorChain.mode
+        self.use_chain = os.environ.get("BASD_SELECTOR_CHAIN", "1") != "0"
+        self.chain_mode = int(os.environ.get("BASD_CHAIN_MODE", "0"))
+        self._chain_plans: dict = {}
 
     def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
         key = (str(device), index)
@@ -963,6 +970,173 @@ class BASDLoss(nn.Module):
             prio = -1 if (mode == "1" and index % 3 < 2) or (mode == "2" and index % 3 == 0) else 0
             self._side_streams[key] = torch.cuda.Stream(device=device, priority=prio)
         return self._side_streams[key]
+
+    def _forward_single_teacher_legacy(self, student_output, targets, students, keys, teachers, attns, comp):
+        """One teacher layer, shapes ``basd_selector_chain`` does not take (fewer teacher tokens than student features:
+        the token-side Gram of layer_selector.py:14-15; the Jacobi eigen-solver): the selector queued kernel by kernel
+        over four streams, its tail one step late (round-2 layout)."""
+        sel = self.layer_selector
+        # One teacher layer (CNN teachers): softmax over a single distance is 1 whatever the distance, so
+        # the Procrustes loss does not depend on the selector.  The selector's eigen-solves are latency-
+        # bound chains of small launches; run them on a side stream underneath the Procrustes kernels.
+        main = torch.cuda.current_stream()
+        # two sets of chain streams, used by alternate steps: with the deferred read-back the chains of
+        # consecutive steps overlap instead of queueing behind each other
+        lane = 0
+        if not self.sync_ranks:
+            lane = self._chain_lane = (getattr(self, "_chain_lane", 1) + 1) % 2
+        side = self._selector_stream(main.device, 3 * lane)
+        side2 = self._selector_stream(main.device, 3 * lane + 1)
+        side.wait_stream(main)
+        # the borrowed inputs are read on the side streams after this call has returned (the tail of the
+        # selector is not joined into the main stream: nothing downstream of it feeds the loss)
+        for t in (*students, *teachers):
+            t.record_stream(side)
+            t.record_stream(side2)
+        with torch.cuda.stream(side):
+            spectra = sel._spectra_async(students, teachers, student_stream=side2, defer_student=True)
+        ops.trace("chains_queued")
+        ce_loss = _base_loss(self.base_criterion, student_output, targets)     # behind the chains' first launches
+        # softmax over ONE logit: the mixing weights are exactly 1 and d loss / d temperature exactly 0
+        mix = ops._device_consts((1.0,) * len(students), torch.float32, main.device).view(-1, 1)
+        total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
+                                                      sel.log_temperatures, teachers, attns, *students)
+        ops.trace("procrustes_queued")
+        # the student chain waits for the teacher's first tridiagonalisation stage on the GPU anyway: queue it now,
+        # behind the Procrustes kernels, instead of in front of them
+        queue_student = spectra.pop("queue_student", None)
+        if queue_student is not None:
+            with torch.cuda.stream(side):
+                queue_student()
+        # what the selector tail of THIS step has to wait for (it may be queued after later steps' chains)
+        chain_done = []
+        for st_ in (side, side2):
+            ev = torch.cuda.Event()
+            ev.record(st_)
+            chain_done.append(ev)
+        tail = self._selector_stream(main.device, 3 * lane + 2)
+
+        def read_ranks_once():
+            # The host reads the ranks here (and raises on rank 0 like the reference).
+            if "rank_ready" in spectra:
+                return sel._read_ranks(spectra, keys)               # waits on the rank kernel's event
+            with torch.cuda.stream(side):                           # plain read-back behind both chains
+                side.wait_stream(side2)
+                return sel._read_ranks(spectra, keys)
+
+        def read_ranks():
+            nonlocal spectra, chain_done
+            try:
+                return read_ranks_once()
+            except TridiagGiveUp as exc:
+                # degrade, do not die: the selector of THIS step once more, one workgroup per matrix
+                _single_member_mode(str(exc))
+                torch.cuda.synchronize(main.device)
+                with torch.cuda.stream(side):
+                    spectra = sel._spectra_async(students, teachers, student_stream=side2)
+                chain_done = []
+                for st_ in (side, side2):
+                    ev = torch.cuda.Event()
+                    ev.record(st_)
+                    chain_done.append(ev)
+                return read_ranks_once()
+
+        def queue_tail(ranks, gate_tail=False):
+            # The rest of the selector (eigenvectors, principal angles) goes to a third stream: the next step's
+            # eigen-solve chains do not queue behind it, and nothing of it feeds this loss when there is one
+            # teacher layer -- so it is not even queued in this call (see below).
+            for ev in chain_done:
+                tail.wait_event(ev)
+            # queued one step later (see below): then also behind that step's multi-workgroup tridiagonalisation
+            # stage, like its student chain -- the members of that stage must not queue for CUs behind these kernels
+            if gate_tail and isinstance(getattr(sel, "_gate_event", None), torch.cuda.Event):
+                tail.wait_event(sel._gate_event)
+            elif gate_tail and getattr(sel, "_gate_event", None) is not None:
+                ops.stream_wait_event(tail, sel._gate_event)
+            ops.trace("tail_waits")
+            # only what the tail reads needs marking (every marked block costs an event when it is freed)
+            _record_stream([spectra.get("t_ts"), spectra.get("s_ts"), spectra["ranks_dev"],
+                            spectra.get("t_stack"), spectra.get("t_colnorm"), spectra.get("s_stack"),
+                            spectra.get("s_colnorm")], tail)
+            ops.trace("tail_marked")
+            spectra["student_stream"] = None
+            with torch.cuda.stream(tail):
+                # layer_selector.py:99-105; nothing of THIS loss reads it (softmax over one distance), so it is
+                # only published: ``last_components["d_grass_sq"]`` of the step, valid after ``finish_pending()``
+                # (written on the tail stream: synchronise the device or that stream before reading)
+                comp["d_grass_sq"] = sel._angles_from_spectra(spectra, keys, ranks_host=ranks)[0]
+            ops.trace("tail_queued")
+
+        def selector_tail():
+            queue_tail(read_ranks())
+        return total, ce_loss, geo_layers, mix, (read_ranks, queue_tail, selector_tail)
+
+    def _chain_plan(self, students, teachers, main) -> "SelectorChainPlan":
+        key = SelectorChainPlan.key(students, teachers, self.chain_mode)
+        plan = self._chain_plans.get(key)
+        if plan is None:
+            if len(self._chain_plans) >= 4:         # shapes changed for good (another resolution): drop the old workspaces
+                torch.cuda.synchronize(main.device)
+                self._chain_plans.clear()
+            streams = tuple(self._selector_stream(main.device, i) for i in range(3))
+            plan = self._chain_plans[key] = SelectorChainPlan(students, teachers, self.chain_mode, streams)
+        return plan
+
+    def _forward_single_teacher(self, student_output, targets, students, keys, teachers, attns, comp):
+        """One teacher layer (every CNN teacher; softmax over a single distance is 1, so the loss does not wait for the
+        selector): the whole selector is ONE library call over three side streams (``basd_selector_chain``), the base
+        loss and the Procrustes loss + unit gradients follow on the caller's stream, then the host waits for the
+        teacher ranks and for nothing else (the reference reads them, and raises on rank 0, inside forward)."""
+        sel = self.layer_selector
+        sel.finish_pending()                   # the previous step's deferred read-back, if that mode is on
+        main = torch.cuda.current_stream()
+        xs = ops._check_common_layout([ops.as_supported(x) for x in students], "student token tensors")
+        plan = self._chain_plan(xs, teachers, main)
+        # the borrowed inputs are read on the side streams after this call has returned
+        for t in (*xs, *teachers):
+            t.record_stream(plan.chain_stream)
+            t.record_stream(plan.student_stream)
+        proj_t = sel.proj_t if sel.proj_t.dtype == torch.float32 and sel.proj_t.is_contiguous() \
+            else sel.proj_t.float().contiguous()
+        ops.gpu_mark("chain_begin")
+        slot = plan.queue(xs, teachers, proj_t, sel._proj_s_transposed(), main.cuda_stream)
+        ops.trace("chains_queued")
+        ce_loss = _base_loss(self.base_criterion, student_output, targets)
+        # softmax over ONE logit: the mixing weights are exactly 1 and d loss / d temperature exactly 0
+        mix = ops._device_consts((1.0,) * len(students), torch.float32, main.device).view(-1, 1)
+        total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
+                                                      sel.log_temperatures, teachers, attns, *students)
+        ops.trace("procrustes_queued")
+
+        def complete():
+            nonlocal slot
+            ranks, status = plan.read_ranks(slot)
+            ops.trace("ranks_read")
+            if status[0]:
+                # workgroups sharing a matrix lost each other (bounded spin): degrade, do not die -- the selector of
+                # THIS step once more with one workgroup per matrix, and keep that setting
+                _single_member_mode("workgroups sharing a matrix timed out waiting for each other "
+                                    f"(device oversubscribed?) [{status}]")
+                torch.cuda.synchronize(main.device)
+                slot = plan.queue(xs, teachers, proj_t, sel._proj_s_transposed(), main.cuda_stream)
+                ranks, status = plan.read_ranks(slot)
+                if status[0]:
+                    raise TridiagGiveUp(f"basd_tridiag: the factorisation failed with one workgroup per matrix [{status}]")
+            sel._subspace_ranks[keys[0]] = int(ranks[0])
+            if min(ranks) == 0:
+                # reference: 0/0 distance -> NaN weights -> NaN tokens -> torch.linalg.svd raises
+                raise torch.linalg.LinAlgError(
+                    "linalg.svd: The algorithm failed to converge because the input matrix contained "
+                    "non-finite values (a teacher layer has Marchenko-Pastur rank 0).")
+            # layer_selector.py:99-105: nothing of THIS loss reads it; published as ``last_components["d_grass_sq"]``
+            # (written on the selector's tail stream: synchronise the device before reading it)
+            comp["d_grass_sq"] = plan.finish_tail(slot, ranks)
+
+        if self.sync_ranks:
+            complete()
+        else:
+            sel._pending_tail = complete
+        return total, ce_loss, geo_layers, mix
 
     # (no torch.compiler.disable wrapper: it costs ~40 us of host time per call on the step's critical path;
     # under torch.compile the ctypes launches graph-break by themselves)
@@ -986,106 +1160,24 @@ class BASDLoss(nn.Module):
         attns = [all_teacher_attns[k] for k in keys]
 
         sel = self.layer_selector
-        if len(keys) == 1:
-            # One teacher layer (CNN teachers): softmax over a single distance is 1 whatever the distance, so
-            # the Procrustes loss does not depend on the selector.  The selector's eigen-solves are latency-
-            # bound chains of small launches; run them on a side stream underneath the Procrustes kernels.
-            main = torch.cuda.current_stream()
-            # two sets of chain streams, used by alternate steps: with the deferred read-back the chains of
-            # consecutive steps overlap instead of queueing behind each other
-            lane = 0
-            if not self.sync_ranks:
-                lane = self._chain_lane = (getattr(self, "_chain_lane", 1) + 1) % 2
-            side = self._selector_stream(main.device, 3 * lane)
-            side2 = self._selector_stream(main.device, 3 * lane + 1)
-            side.wait_stream(main)
-            # the borrowed inputs are read on the side streams after this call has returned (the tail of the
-            # selector is not joined into the main stream: nothing downstream of it feeds the loss)
-            for t in (*students, *teachers):
-                t.record_stream(side)
-                t.record_stream(side2)
-            with torch.cuda.stream(side):
-                spectra = sel._spectra_async(students, teachers, student_stream=side2, defer_student=True)
-            ops.trace("chains_queued")
-            ce_loss = _base_loss(self.base_criterion, student_output, targets)     # behind the chains' first launches
-            # softmax over ONE logit: the mixing weights are exactly 1 and d loss / d temperature exactly 0
-            mix = ops._device_consts((1.0,) * len(students), torch.float32, main.device).view(-1, 1)
-            total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
-                                                          sel.log_temperatures, teachers, attns, *students)
-            ops.trace("procrustes_queued")
-            # the student chain waits for the teacher's first tridiagonalisation stage on the GPU anyway: queue it now,
-            # behind the Procrustes kernels, instead of in front of them
-            queue_student = spectra.pop("queue_student", None)
-            if queue_student is not None:
-                with torch.cuda.stream(side):
-                    queue_student()
-            # what the selector tail of THIS step has to wait for (it may be queued after later steps' chains)
-            chain_done = []
-            for st_ in (side, side2):
-                ev = torch.cuda.Event()
-                ev.record(st_)
-                chain_done.append(ev)
-            tail = self._selector_stream(main.device, 3 * lane + 2)
-
-            def read_ranks_once():
-                # The host reads the ranks here (and raises on rank 0 like the reference).
-                if "rank_ready" in spectra:
-                    return sel._read_ranks(spectra, keys)               # waits on the rank kernel's event
-                with torch.cuda.stream(side):                           # plain read-back behind both chains
-                    side.wait_stream(side2)
-                    return sel._read_ranks(spectra, keys)
-
-            def read_ranks():
-                nonlocal spectra, chain_done
-                try:
-                    return read_ranks_once()
-                except TridiagGiveUp as exc:
-                    # degrade, do not die: the selector of THIS step once more, one workgroup per matrix
-                    _single_member_mode(str(exc))
-                    torch.cuda.synchronize(main.device)
-                    with torch.cuda.stream(side):
-                        spectra = sel._spectra_async(students, teachers, student_stream=side2)
-                    chain_done = []
-                    for st_ in (side, side2):
-                        ev = torch.cuda.Event()
-                        ev.record(st_)
-                        chain_done.append(ev)
-                    return read_ranks_once()
-
-            def queue_tail(ranks, gate_tail=False):
-                # The rest of the selector (eigenvectors, principal angles) goes to a third stream: the next step's
-                # eigen-solve chains do not queue behind it, and nothing of it feeds this loss when there is one
-                # teacher layer -- so it is not even queued in this call (see below).
-                for ev in chain_done:
-                    tail.wait_event(ev)
-                # queued one step later (see below): then also behind that step's multi-workgroup tridiagonalisation
-                # stage, like its student chain -- the members of that stage must not queue for CUs behind these kernels
-                if gate_tail and isinstance(getattr(sel, "_gate_event", None), torch.cuda.Event):
-                    tail.wait_event(sel._gate_event)
-                elif gate_tail and getattr(sel, "_gate_event", None) is not None:
-                    ops.stream_wait_event(tail, sel._gate_event)
-                ops.trace("tail_waits")
-                # only what the tail reads needs marking (every marked block costs an event when it is freed)
-                _record_stream([spectra.get("t_ts"), spectra.get("s_ts"), spectra["ranks_dev"],
-                                spectra.get("t_stack"), spectra.get("t_colnorm"), spectra.get("s_stack"),
-                                spectra.get("s_colnorm")], tail)
-                ops.trace("tail_marked")
-                spectra["student_stream"] = None
-                with torch.cuda.stream(tail):
-                    sel._angles_from_spectra(spectra, keys, ranks_host=ranks)
-                ops.trace("tail_queued")
-
-            def selector_tail():
-                queue_tail(read_ranks())
+        comp: dict[str, torch.Tensor] = {}          # this step's ``last_components`` (the selector tail fills d_grass_sq)
+        selector_tail = None
+        if len(keys) == 1 and self.use_chain and SelectorChainPlan.supported(students, teachers):
+            total, ce_loss, geo_layers, mix = self._forward_single_teacher(student_output, targets, students, keys,
+                                                                           teachers, attns, comp)
+        elif len(keys) == 1:
+            total, ce_loss, geo_layers, mix, (read_ranks, queue_tail, selector_tail) = \
+                self._forward_single_teacher_legacy(student_output, targets, students, keys, teachers, attns, comp)
         else:
-            selector_tail = None
             sel.finish_pending()
             ce_loss = _base_loss(self.base_criterion, student_output, targets)
             mix = sel.mixing_weights(students, keys, teachers)
             geo_layers = _ProcrustesLayers.apply(mix, bool(self.teacher_has_cls_token), False, None, teachers, attns,
                                                  *students)
             total = _UWSOCombine.apply(ce_loss, geo_layers)
-        self.last_components = {"ce": ce_loss.detach(), "geo_layers": geo_layers.detach(), "mix": mix.detach()}
+            comp["d_grass_sq"] = sel._last_d_grass_sq
+        comp.update(ce=ce_loss.detach(), geo_layers=geo_layers.detach(), mix=mix.detach())
+        self.last_components = comp
         ops.trace("combine_queued")
         if selector_tail is not None:
             if self.sync_ranks:

@@ -484,19 +484,26 @@ def _ptr_table(tensors: list[torch.Tensor]) -> torch.Tensor:
 
 
 _CONSTS: dict = {}
+_CONSTS_RETIRED: list = []       # older generations of the cache, kept alive (see below)
+_CONSTS_LIMIT = 512
 
 
 def _device_consts(values: tuple, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
     """Small read-only device arrays (pointer tables, per-matrix scales), cached by value: the caching
-    allocator hands the same addresses back every step, so the steady state uploads nothing."""
+    allocator hands the same addresses back every step, so the steady state uploads nothing.
+
+    The tables are read by kernels on several streams (chains, tail, caller) without ``record_stream``, so their memory
+    must not be handed out again while a queued reader may still run.  No device-wide wait for that (it would stall
+    training every ~100 steps once input addresses churn): a full cache is RETIRED, not freed -- the two most recent
+    retired generations stay alive, i.e. a table is released no sooner than 2 x 512 newer distinct tables later.  Every
+    loss step makes the host wait for that step's rank kernel, so no stream is ever more than a few steps behind the
+    host; a thousand tables later (hundreds of steps) every reader is long done."""
     key = (values, dtype, device)
     t = _CONSTS.get(key)
     if t is None:
-        if len(_CONSTS) > 512:
-            # The tables are read by kernels on several streams (chains, tail, caller) without record_stream: before
-            # their memory may be handed out again every queued reader must be done.  Rare (input addresses churning:
-            # once per ~100 steps at five new tables a step), so a device-wide wait is the simple safe choice.
-            torch.cuda.synchronize(device)
+        if len(_CONSTS) >= _CONSTS_LIMIT:
+            _CONSTS_RETIRED.append(dict(_CONSTS))
+            del _CONSTS_RETIRED[:-2]
             _CONSTS.clear()
         t = torch.tensor(values, dtype=dtype).to(device)
         _CONSTS[key] = t
@@ -601,8 +608,9 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
         sweeps.zero_()
     # cores whose 2n rows are past LDS while n rows fit: rotation log of the two-pass SVD (0 bytes: shape not covered)
     jac_bytes = _lib.query("basd_jacobi_twopass_workspace_bytes", n, EB, MAX_SWEEPS) if TWO_PASS_SVD else 0
-    if jac_bytes > TWO_PASS_LOG_LIMIT:       # very large batches: the block solver needs no log
-        jac_bytes = 0
+    if jac_bytes > TWO_PASS_LOG_LIMIT or (jac_bytes > (256 << 20)
+                                          and jac_bytes > torch.cuda.mem_get_info(dev)[0] // 2):
+        jac_bytes = 0       # very large batches / little free memory: the block solver needs no log
     jac_ws = torch.empty((jac_bytes // 8 + 1,), device=dev, dtype=torch.int64) if jac_bytes > 0 else None
     raw = torch.empty((G, B, n_a), **f32) if need_mix_grad else None
     h = dx = uw = None

@@ -1,0 +1,192 @@
+// The Grassmannian layer selector of one loss step (reference layer_selector.py:69-74, :86-105, :131-138) queued by ONE
+// library call over three streams: projections and Gram matrices (fp32 MFMA), the Householder tridiagonalisation of
+// all 2L + E matrices with the Marchenko-Pastur ranks written to pinned host memory by the kernel that finishes the
+// factorisation, and -- without waiting for the host -- the rest of the selector with the ranks read ON THE DEVICE:
+// spectra, leading eigenvectors, principal angles, d_grass_sq.
+//
+// Why one call: round 2 queued this from Python (~40 torch.empty, ~15 FFI calls, event objects): the host needed 0.7 ms
+// per step and the first chain kernel started 0.28 ms after the loss was entered; every one of those microseconds sits
+// in front of the chain the host then waits for.  Why device-side ranks: the part behind the rank read-back used to be
+// sized by the host (kmax = max rank) and was therefore queued one step late; here it is sized by a HINT (the previous
+// step's largest rank) and every kernel takes the actual rank from device memory -- correct for any hint >= the
+// largest rank; the caller re-queues the tail (basd_selector_chain_tail) in the rare step where the rank grew past it.
+#include "basd_common.h"
+#include "../../include/basd_hip.h"
+
+namespace basd {
+
+// sw[l][i] = sqrt(max(lambda_i, 0)), i < kmax: singular values S[:k] of the centred projected teacher tokens from the
+// eigenvalues of their Gram (layer_selector.py:36-37).  grid = L, block = 256.
+__global__ void __launch_bounds__(256) chain_sw_kernel(const float* __restrict__ vals, int n, int kmax,
+                                                       float* __restrict__ sw) {
+    const int l = blockIdx.x;
+    for (int i = threadIdx.x; i < kmax; i += 256) sw[(long)l * kmax + i] = sqrtf(fmaxf(vals[(long)l * n + i], 0.f));
+}
+
+// k_arr[e * L + l] = ranks[l] (clamped to [1, kmax]: a rank-0 layer raises on the host, layer_selector.py:105 would
+// divide 0 by 0; a rank past the hint is re-queued by the caller -- neither result is ever observed).
+__global__ void chain_k_arr_kernel(const int* __restrict__ ranks, int L, int items, int kmax, int* __restrict__ k_arr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < items) {
+        int k = ranks[i % L];
+        k = k < 1 ? 1 : k;
+        k_arr[i] = k > kmax ? kmax : k;
+    }
+}
+
+}  // namespace basd
+
+#define BASD_TRY(call)                \
+    do {                              \
+        int rc_ = (call);             \
+        if (rc_ != BASD_OK) return rc_; \
+    } while (0)
+#define BASD_HIP(call)                          \
+    do {                                        \
+        hipError_t e_ = (call);                 \
+        if (e_ != hipSuccess) return (int)e_;   \
+    } while (0)
+
+extern "C" {
+
+int basd_event_record(void* ev, hipStream_t stream) {
+    BASD_CHECK_ARG(ev);
+    BASD_HIP(hipEventRecord((hipEvent_t)ev, stream));
+    return BASD_OK;
+}
+int basd_event_synchronize(void* ev) {
+    BASD_CHECK_ARG(ev);
+    BASD_HIP(hipEventSynchronize((hipEvent_t)ev));
+    return BASD_OK;
+}
+// 1 when everything recorded before the event has completed, 0 when not yet
+int basd_event_query(void* ev) {
+    if (!ev) return BASD_EINVAL;
+    const hipError_t e = hipEventQuery((hipEvent_t)ev);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return BASD_EINVAL;
+}
+
+// layer_selector.py:36-37, :92, :95-105 for the matrices of one chain: spectra of the L centred teacher and E student
+// Grams, their leading kmax eigenvectors, S[:k], the rotation of the teacher bases by proj_s^T (proj_s is orthogonal:
+// folded from :88 into :99), the E x L cosine matrices, their singular values of order ranks[l] and d_grass_sq (E, L).
+// Queued on a->tail_stream behind ev_ranks (and ev_student in the split modes); records ev_tail.
+int basd_selector_chain_tail(const BasdSelectorChain* a, int kmax, int exact_k) {
+    BASD_CHECK_ARG(a && a->d && a->vals && a->zv && a->vecs && a->u_rot && a->sw && a->cos && a->sigma && a->d_out &&
+                   a->k_arr && a->sw_index && a->jflags && a->ranks && a->proj_s_t);
+    const int E = (int)a->E, L = (int)a->L, n = (int)a->d_s;
+    BASD_CHECK_ARG(E > 0 && L > 0 && kmax > 0 && kmax <= n && kmax <= (int)a->kmax_cap);
+    if (!exact_k && !basd_jacobi_lds_square_fits(kmax)) return BASD_EUNSUPPORTED;
+    hipStream_t st = a->tail_stream;
+    BASD_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_ranks, 0));
+    if (a->mode != 0) BASD_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_student, 0));
+    const long nn = (long)n * n, kn = (long)kmax * n, kk = (long)kmax * kmax;
+    // matrices [L, 2L + E): centred teacher Grams, then the student Grams
+    const float* dz = a->d + (long)L * n;
+    const float* ez = a->e + (long)L * n;
+    const float* tz = a->tau + (long)L * n;
+    const float* vz = a->vh + (long)L * nn;
+    float* lam = a->vals + (long)L * n;
+    BASD_TRY(basd_tridiag_eigenvalues(dz, ez, n, L + E, lam, st));
+    // rows of vecs: (L + E, kmax, n) -- teacher bases first, then Vt_s[:kmax] of every student layer
+    BASD_TRY(basd_tridiag_eigenvectors(dz, ez, tz, vz, lam, n, kmax, L + E, a->zv, a->vecs, kmax, st));
+    basd::chain_sw_kernel<<<L, 256, 0, st>>>(lam, n, kmax, a->sw);
+    const float* u_t = a->vecs;
+    const float* v_s = a->vecs + (long)L * kn;
+    BASD_TRY(basd_gemm_nt(u_t, BASD_DTYPE_F32, 0, n, 1, 1 << 30, 0, a->proj_s_t, n, 0, L * kmax, n, n, 1, a->u_rot, n,
+                          (long)L * kn, 1.f, nullptr, 0.f, nullptr, nullptr, st));
+    if (L == 1) {
+        BASD_TRY(basd_gemm_nt(v_s, BASD_DTYPE_F32, 0, n, 1, 1 << 30, kn, a->u_rot, n, 0, kmax, kmax, n, E, a->cos, kmax,
+                              kk, 1.f, nullptr, 0.f, nullptr, nullptr, st));
+    } else {
+        for (int e = 0; e < E; ++e)
+            BASD_TRY(basd_gemm_nt(v_s + e * kn, BASD_DTYPE_F32, 0, n, 1, 1 << 30, 0, a->u_rot, n, kn, kmax, kmax, n, L,
+                                  a->cos + (long)e * L * kk, kmax, kk, 1.f, nullptr, 0.f, nullptr, nullptr, st));
+    }
+    const int items = E * L;
+    basd::chain_k_arr_kernel<<<(items + 255) / 256, 256, 0, st>>>(a->ranks, L, items, kmax, a->k_arr);
+    BASD_TRY(basd_jacobi_onesided(a->cos, kk, kmax, kmax, kmax, items, exact_k ? nullptr : a->k_arr, a->sigma, kmax, 20,
+                                  0.f, a->jflags, nullptr, st));
+    BASD_TRY(basd_grassmann_distance(a->sigma, kmax, a->k_arr, a->sw, kmax, a->sw_index, items, a->d_out, nullptr, st));
+    BASD_HIP(hipEventRecord((hipEvent_t)a->ev_tail, st));
+    return BASD_OK;
+}
+
+int basd_selector_chain(const BasdSelectorChain* a) {
+    BASD_CHECK_ARG(a && a->teacher_host_ptrs && a->student_ptrs && a->proj_t && a->z && a->z_sums && a->z_ptrs &&
+                   a->t_scales && a->t_slabs && a->s_partial && a->s_means && a->s_slabs && a->grams && a->d && a->e &&
+                   a->tau && a->vh && a->tri_work && a->ranks && a->ev_fork && a->ev_student && a->ev_ranks && a->ev_tail);
+    const int E = (int)a->E, L = (int)a->L, B = (int)a->B, n_s = (int)a->n_s, n_t = (int)a->n_t;
+    const int n = (int)a->d_s, d_t = (int)a->d_t, mode = (int)a->mode;
+    BASD_CHECK_ARG(E > 0 && L > 0 && B > 0 && n > 1 && d_t > 0 && mode >= 0 && mode <= 2);
+    const long M_t = (long)B * n_t, M_s = (long)B * n_s;
+    // the uncentred Gram is formed on the feature side (layer_selector.py:12-13); the token-side form (:14-15, fewer
+    // rows than features) has a different order: not covered here, the caller takes the per-kernel entry points
+    if (M_t < n || M_t > 0x7fffffff || M_s > 0x7fffffff) return BASD_EUNSUPPORTED;
+    const long nn = (long)n * n;
+    const int tiles = (int)((M_t + 127) / 128);
+    hipStream_t cs = a->chain_stream, ss = a->student_stream;
+
+    // ---- order against the caller: inputs are ready on main_stream; this slot's buffers are free once the tail that
+    // read them last has finished
+    BASD_HIP(hipEventRecord((hipEvent_t)a->ev_fork, a->main_stream));
+    BASD_HIP(hipStreamWaitEvent(cs, (hipEvent_t)a->ev_fork, 0));
+    if (ss != cs) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_fork, 0));
+    if (a->ev_slot_free) {
+        BASD_HIP(hipStreamWaitEvent(cs, (hipEvent_t)a->ev_slot_free, 0));
+        if (ss != cs) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_slot_free, 0));
+    }
+
+    // ---- teacher: z_l = tokens_l proj_t^T (+ column sums of every 128-row tile), then both Grams of every layer in one
+    // symmetric launch: [uncentred / M x L, centred x L]                                (layer_selector.py:72, :13, :35)
+    for (int l = 0; l < L; ++l)
+        BASD_TRY(basd_gemm_nt(a->teacher_host_ptrs[l], (int)a->t_dtype, a->t_sb, a->t_sn, a->t_sd, n_t, 0, a->proj_t, d_t,
+                              0, (int)M_t, n, d_t, 1, a->z + (long)l * M_t * n, n, M_t * n, 1.f, nullptr, 0.f,
+                              a->z_sums + (long)l * tiles * n, nullptr, cs));
+    BASD_TRY(basd_syrk_multi(a->z_ptrs, BASD_DTYPE_F32, 0, n, 1, 1 << 30, (int)M_t, n, 2 * L, nullptr, a->t_scales,
+                             (int)a->t_splits, a->t_slabs, a->grams, nn, 1, a->z_sums, tiles, L, cs));
+
+    auto student_grams = [&](hipStream_t st) -> int {
+        // centred Grams of the E student layers (:88-91; proj_s folded into the principal angles)
+        BASD_TRY(basd_colmean_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, a->s_sd, n_s, (int)M_s, n, E,
+                                    (int)a->s_parts, a->s_partial, a->s_means, (int)a->s_vec_ok, st));
+        BASD_TRY(basd_syrk_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, a->s_sd, n_s, (int)M_s, n, E,
+                                 a->s_means, nullptr, (int)a->s_splits, a->s_slabs, a->grams + 2L * L * nn, nn,
+                                 (int)a->s_vec_ok, nullptr, 0, 0, st));
+        return BASD_OK;
+    };
+
+    if (mode == 0) {
+        // ONE factorisation launch over all 2L + E matrices: the student Grams join the teacher's before it
+        BASD_TRY(student_grams(ss));
+        if (ss != cs) {
+            BASD_HIP(hipEventRecord((hipEvent_t)a->ev_student, ss));
+            BASD_HIP(hipStreamWaitEvent(cs, (hipEvent_t)a->ev_student, 0));
+        }
+        BASD_TRY(basd_tridiag_ranked(a->grams, nn, n, 2 * L + E, a->d, a->e, a->tau, a->vh, a->tri_work, L, a->mp_factor,
+                                     (int)a->rank_cap, a->ranks, a->host_mirror, nullptr, cs));
+        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_ranks, cs));
+    } else {
+        // teacher matrices first (the host waits for their ranks); the student side on its own stream, in mode 1 held
+        // back until the ranks are out (its Gram launch is the largest MFMA launch of the step)
+        BASD_TRY(basd_tridiag_ranked(a->grams, nn, n, 2 * L, a->d, a->e, a->tau, a->vh, a->tri_work, L, a->mp_factor,
+                                     (int)a->rank_cap, a->ranks, a->host_mirror, nullptr, cs));
+        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_ranks, cs));
+        BASD_CHECK_ARG(a->tri_work_s != nullptr && ss != cs);
+        if (mode == 1) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_ranks, 0));
+        BASD_TRY(student_grams(ss));
+        BASD_TRY(basd_tridiag(a->grams + 2L * L * nn, nn, n, E, a->d + 2L * L * n, a->e + 2L * L * n,
+                              a->tau + 2L * L * n, a->vh + 2L * L * nn, a->tri_work_s, ss));
+        if (a->student_status_mirror) {
+            // status words of the student factorisation (last 32 bytes of its workspace): read by the host a step later
+            const char* err = (const char*)a->tri_work_s + basd_tridiag_workspace_bytes(n, E) - 32;
+            BASD_HIP(hipMemcpyAsync(a->student_status_mirror, err, 32, hipMemcpyDeviceToHost, ss));
+        }
+        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_student, ss));
+    }
+    if (a->kmax > 0) return basd_selector_chain_tail(a, (int)a->kmax, 0);
+    return BASD_OK;
+}
+
+}  // extern "C"

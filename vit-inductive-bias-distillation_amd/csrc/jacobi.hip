@@ -646,6 +646,17 @@ int basd_jacobi_plain4_fits(int n) {
     return 0;
 }
 
+// 1 when basd_jacobi_onesided keeps square matrices of order n in LDS with 16 lanes per column pair: the only form that
+// takes per-matrix orders (n_arr), i.e. the principal-angle matrices of basd_selector_tail / basd_selector_chain_tail.
+int basd_jacobi_lds_square_fits(int n) {
+    if (n < 1) return 0;
+    const int n_even = (n + 1) & ~1, epl = (n + 15) / 16;
+    static const int lds_epl[] = {2, 4, 6, 8, 12, 16, 20};
+    for (int e : lds_epl)
+        if (e >= epl) return (size_t)n_even * (16 * e + 4) * sizeof(float) <= BASD_JACOBI_LDS_LIMIT;
+    return 0;
+}
+
 // Test / tuning hook: lanes per column pair of the LDS-resident solver -- 0 = automatic, 4 / 8 / 16 = forced where the
 // shape allows (4 and 8: stacked matrices only).  Process-wide.
 static int g_jacobi_lanes = 0;

@@ -191,10 +191,18 @@ __global__ void __launch_bounds__(256) cross_entropy_kernel(const T* __restrict_
     } else {
         cnt = (float)B;
     }
-    const float inv_count = 1.f / fmaxf(cnt, 1.f);
+    // no row counts (every label is ignore_index): torch's mean is 0 / 0 = NaN
+    const float inv_count = cnt > 0.f ? 1.f / cnt : __builtin_nanf("");
     if (ignored) {
         for (int c = tid; c < C; c += 256) dx[c] = 0.f;
-        if (tid == 0) row_loss[b] = 0.f;
+        if (tid == 0) row_loss[b] = cnt > 0.f ? 0.f : __builtin_nanf("");
+        return;
+    }
+    if (labels && (y < 0 || y >= C)) {
+        // a class index outside [0, C) that is not ignore_index: torch device-asserts; here the loss turns NaN (it
+        // cannot be missed) and nothing is read out of bounds
+        for (int c = tid; c < C; c += 256) dx[c] = 0.f;
+        if (tid == 0) row_loss[b] = __builtin_nanf("");
         return;
     }
     float m = -3.4e38f;
@@ -205,25 +213,37 @@ __global__ void __launch_bounds__(256) cross_entropy_kernel(const T* __restrict_
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
-    float s = 0.f, sx = 0.f, tx = 0.f;          // sum exp, sum x (uniform part), sum t x (target part)
+    float s = 0.f, sx = 0.f, tx = 0.f, st = 0.f;   // sum exp, sum x (uniform part), sum t x (target part), sum t
     for (int c = tid; c < C; c += 256) {
         const float v = to_f32(x[c]) - m;
         s += expf(v);
         sx += v;
-        if (probs) tx = fmaf(probs[(long)b * pld + c], v, tx);
+        if (probs) {
+            const float t = probs[(long)b * pld + c];
+            tx = fmaf(t, v, tx);
+            st += t;
+        }
     }
     s = block_sum(s, red);
     sx = block_sum(sx, red);
-    if (probs) tx = block_sum(tx, red);
-    else tx = to_f32(x[y]) - m;
+    if (probs) {
+        tx = block_sum(tx, red);
+        st = block_sum(st, red);
+    } else {
+        tx = to_f32(x[y]) - m;
+        st = 1.f;
+    }
     const float lse = logf(s);
-    // -sum_c t'_c (v_c - lse) = lse - (1 - eps) tx - eps/C sx        (sum_c t'_c = 1); already divided by the count
-    if (tid == 0) row_loss[b] = (lse - (1.f - eps) * tx - eps / (float)C * sx) * inv_count;
+    // -sum_c t'_c (v_c - lse) with t' = (1 - eps) t + eps / C:  lse * sum t' - (1 - eps) tx - eps/C sx, where
+    // sum t' = (1 - eps) sum t + eps (soft targets need not be normalised: torch does not assume it either);
+    // already divided by the count
+    const float sum_tp = fmaf(1.f - eps, st, eps);
+    if (tid == 0) row_loss[b] = (lse * sum_tp - (1.f - eps) * tx - eps / (float)C * sx) * inv_count;
     const float inv_s = 1.f / s;
     for (int c = tid; c < C; c += 256) {
         const float p = expf(to_f32(x[c]) - m) * inv_s;
         const float t = probs ? probs[(long)b * pld + c] : (c == y ? 1.f : 0.f);
-        dx[c] = (p - ((1.f - eps) * t + eps / (float)C)) * inv_count;
+        dx[c] = (p * sum_tp - ((1.f - eps) * t + eps / (float)C)) * inv_count;
     }
 }
 }  // namespace basd
