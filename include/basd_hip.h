@@ -272,6 +272,11 @@ typedef struct BasdSelectorChain {
     int* k_arr; const int* sw_index; int* jflags;
     hipStream_t main_stream, chain_stream, student_stream, tail_stream;
     void* ev_fork; void* ev_student; void* ev_ranks; void* ev_tail; void* ev_slot_free;
+    /* measurement (all nullable; timed events of basd_event_create_timed, recorded on the stream of the launch they
+     * bracket): tm_proj = behind the projections, tm_tgram = behind the teacher Grams, tm_scol0 / tm_scol1 = around the
+     * student column means, tm_sgram = behind the student Grams, tm_tri0 = in front of the factorisation (ev_ranks ends
+     * it), tm_mid = between its two stages, tm_spec = behind the spectra at the head of the tail */
+    void* tm_proj; void* tm_tgram; void* tm_scol0; void* tm_scol1; void* tm_sgram; void* tm_tri0; void* tm_mid; void* tm_spec;
 } BasdSelectorChain;
 int basd_selector_chain(const BasdSelectorChain* args);
 /* exact_k != 0: the caller has READ the ranks and every one of them equals kmax (one teacher layer): the principal-angle
@@ -454,6 +459,9 @@ int basd_stream_wait_event(hipStream_t stream, void* event);
 int basd_event_record(void* event, hipStream_t stream);
 int basd_event_synchronize(void* event);      /* blocks the calling host thread */
 int basd_event_query(void* event);            /* 1 = reached, 0 = not yet, < 0 = invalid */
+/* diagnostics: events that carry a time stamp (basd_event_create makes them without), and the time between two */
+int basd_event_create_timed(void** out);
+int basd_event_elapsed_ms(void* from, void* to, float* ms_out);
 
 /* ---- multi-layer teachers only: gradients through the mixing weights and the principal angles ------ */
 

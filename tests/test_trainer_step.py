@@ -52,19 +52,21 @@ def _structured_images(B, size, seed):
 
 def _toy_models(kind, dev="cpu"):
     from basd_amd import trainer as T
+    from tools import stock_models as SM
     torch.manual_seed(3)
-    student = T.StockViT(img_size=32, patch_size=8, embed_dim=48, depth=6, num_heads=4, num_classes=10).to(dev)
+    student = SM.StockViT(img_size=32, patch_size=8, embed_dim=48, depth=6, num_heads=4, num_classes=10).to(dev)
     if kind == "cnn":
-        teacher = T.StockResNet(layers=(1, 1, 1, 1), bottleneck=False, width=16).to(dev)   # 128 channels, 1 x 1 map at 32^2
+        teacher = SM.StockResNet(layers=(1, 1, 1, 1), bottleneck=False, width=16).to(dev)   # 128 channels, 1 x 1 map at 32^2
     else:
-        teacher = T.StockViT(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=0).to(dev)
-    return student, T.make_teacher(teacher, 32)
+        teacher = SM.StockViT(img_size=32, patch_size=8, embed_dim=64, depth=3, num_heads=4, num_classes=0).to(dev)
+    return student, SM.make_teacher(teacher, 32)
 
 
 def test_stock_models_expose_the_probed_layout():
     from basd_amd import trainer as T
+    from tools import stock_models as SM
     student, teacher = _toy_models("cnn")
-    info = T.probe_model(student, 32)
+    info = SM.probe_model(student, 32)
     assert info["layer_paths"] == [f"blocks.{i}" for i in range(6)] and info["attn_subpath"] == "attn"
     assert info["has_cls_token"] and info["feature_format"] == "token" and info["num_tokens"] == 16
     assert info["embed_dim"] == 48 and info["heads_per_layer"] == [4] * 6 and info["mlp_ratio"] == 4.0
@@ -73,14 +75,15 @@ def test_stock_models_expose_the_probed_layout():
     assert not any(p.requires_grad for p in teacher.model.parameters()) and not teacher.model.training
     # DeiT-S / ResNet-50 at the BASELINE shapes (meta device: nothing is allocated)
     with torch.device("meta"):
-        deit_s = T.StockViT()
-        r50 = T.StockResNet()
+        deit_s = SM.StockViT()
+        r50 = SM.StockResNet()
     assert sum(p.numel() for p in deit_s.parameters()) == 22_050_664          # the all-reduce volume bench.py uses
     assert r50.num_features == 2048 and sum(p.numel() for p in r50.parameters()) == 23_508_032
 
 
 def test_mixup_cutmix_targets():
     from basd_amd import trainer as T
+    from tools import stock_models as SM
     torch.manual_seed(0)
     x = torch.randn(8, 3, 16, 16)
     y = torch.arange(8) % 5
@@ -93,9 +96,10 @@ def test_mixup_cutmix_targets():
 @pytest.mark.parametrize("kind", ["cnn", "vit"])
 def test_train_step_on_cpu_with_the_oracle_loss(kind):
     from basd_amd import trainer as T
+    from tools import stock_models as SM
     student, teacher = _toy_models(kind)
     torch.manual_seed(42)
-    tr = T.Trainer(student, _config(), teacher, student_info=T.probe_model(student, 32), loss_cls=OracleBASD)
+    tr = T.Trainer(student, _config(), teacher, student_info=SM.probe_model(student, 32), loss_cls=OracleBASD)
     assert tr.basd_loss.token_layers == [0, 2, 3, 5]
     assert len(tr.optimizer.param_groups) == 2 and tr.optimizer.param_groups[1]["params"][0] is tr.basd_loss.log_temperatures
     before = [p.detach().clone() for p in student.parameters()]
@@ -117,6 +121,7 @@ def _rank_worker(rank, world, port, out):
     for p in (ROOT, os.path.join(ROOT, "vit-inductive-bias-distillation_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     from basd_amd import trainer as T
+    from tools import stock_models as SM
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -125,7 +130,7 @@ def _rank_worker(rank, world, port, out):
         torch.manual_seed(100 + rank)                  # different seeds: the constructor must make the replicas equal
         for p in student.parameters():
             p.data.add_(0.01 * torch.randn_like(p))
-        tr = T.Trainer(student, _config(), teacher, student_info=T.probe_model(student, 32), loss_cls=OracleBASD,
+        tr = T.Trainer(student, _config(), teacher, student_info=SM.probe_model(student, 32), loss_cls=OracleBASD,
                        mixup=False)
         data = torch.utils.data.TensorDataset(_structured_images(16, 32, 7), torch.arange(16) % 10)
         loader = T.shard_loader(data, 4, shuffle=False)
@@ -136,8 +141,34 @@ def _rank_worker(rank, world, port, out):
         flat = torch.cat([p.detach().reshape(-1) for p in student.parameters()] + [tr.basd_loss.log_temperatures.detach()])
         gathered = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(gathered, flat)
+        # every gradient still IS its slice of the flat bucket (no pack / unpack copies were needed)
+        buf = tr._bucket.buffer
+        lo, hi = buf.data_ptr(), buf.data_ptr() + 4 * buf.numel()
+        in_bucket = all(p.grad is not None and lo <= p.grad.data_ptr() < hi
+                        for p in list(student.parameters()) + [tr.basd_loss.log_temperatures])
+        # a shuffling sharded loader: ``_train_epoch`` hands the epoch to its sampler, so two epochs see different orders
+        imgs, labels = _structured_images(16, 32, 9), torch.arange(16) % 10
+
+        class Recording(torch.utils.data.Dataset):
+            seen: list = []
+
+            def __len__(self):
+                return 16
+
+            def __getitem__(self, i):
+                self.seen.append(int(i))
+                return {"clean": imgs[i], "augmented": imgs[i], "label": labels[i]}
+
+        rec = Recording()
+        shuffled = T.shard_loader(rec, 4, seed=3)
+        orders = []
+        for epoch in range(2):
+            rec.seen = []
+            tr._train_epoch(shuffled, epoch)
+            orders.append(list(rec.seen))
         out[rank] = (all(torch.equal(g, gathered[0]) for g in gathered), len(seen),
-                     float((tr.basd_loss.log_temperatures.detach() - 0.5413).abs().max()))
+                     float((tr.basd_loss.log_temperatures.detach() - 0.5413).abs().max()), in_bucket,
+                     tr.reattached, orders[0] != orders[1], orders[0])
     finally:
         dist.destroy_process_group()
 
@@ -149,8 +180,11 @@ def test_two_ranks_stay_identical_including_the_temperatures():
     out = mp.Manager().dict()
     mp.spawn(_rank_worker, args=(world, port, out), nprocs=world, join=True)
     assert len(out) == world
-    for same, n_seen, moved in out.values():
+    for same, n_seen, moved, in_bucket, reattached, reshuffled, _ in out.values():
         assert same and n_seen == 8 and moved > 1e-5
+        assert in_bucket and reattached == 0            # gradient views: nothing was copied into or out of the bucket
+        assert reshuffled
+    assert not set(out[0][6]) & set(out[1][6])          # the two ranks' shards are disjoint
 
 
 @pytest.fixture(scope="module")
@@ -166,10 +200,11 @@ def test_train_step_on_the_hip_library(dev, kind, autocast):
     """A full step on the GPU; the loss of the captured tensors agrees with the oracle (fp32 capture) and the
     checkpoint round trip restores the step counter and the selector state."""
     from basd_amd import trainer as T, capture
+    from tools import stock_models as SM
     from oracle import basd_oracle as O
     student, teacher = _toy_models(kind, dev)
     torch.manual_seed(42)
-    tr = T.Trainer(student, _config(), teacher, student_info=T.probe_model(student, 32), autocast_dtype=autocast,
+    tr = T.Trainer(student, _config(), teacher, student_info=SM.probe_model(student, 32), autocast_dtype=autocast,
                    mixup=False)
     batch = {"clean": _structured_images(16, 32, 1), "augmented": _structured_images(16, 32, 2),
              "label": torch.arange(16) % 10}

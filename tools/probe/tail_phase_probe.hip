@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(basd::g_tail_dbg), sizeof(long long) * 2 * 8 * 2 * 1024);
     const int OFF = 8 * 2 * 1024;      // basd_tridiag delivers no ranks: second stamp set
     const char* names[] = {"pass", "A-wait", "sum", "scalar", "reflector", "B-wait"};
-    for (int jl : {2, 64, 128, 200, 250}) {
+    for (int jl : {2, 64, 128, 200, 250, 300, 350}) {
         if (jl >= n - 2) continue;
         for (int w = 0; w < 2; ++w) {
             printf("step %3d wave %s:", jl, w ? "last" : "0   ");

@@ -7,7 +7,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "vit-inductive-bias-distillation_amd"))
 import torch
 import bench
-from basd_amd import ops, synth, ddp
+from basd_amd import ops, synth, ddp, chain, _lib
+chain.TIMED_EVENTS = True
+chain.TIMING = []
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 shape = synth.CONFIGS[cfg]
@@ -22,10 +24,13 @@ for _ in range(8):
 torch.cuda.synchronize()
 ref = torch.cuda.Event(enable_timing=True)
 ref.record()
+ref_raw = chain._event(True)
+_lib.call("basd_event_record", ref_raw, torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 t_ref = time.perf_counter()
 N = 30
-host, gpu = [], []
+host, gpu, raw = [], [], []
+plans = lambda: list(mod._chain_plans.values())
 for it in range(N):
     ops.HOST_TRACE, ops.GPU_MARKS = [], []
     t0 = time.perf_counter()
@@ -34,13 +39,27 @@ for it in range(N):
     ops.trace("step_out")
     host.append((t0, ops.HOST_TRACE))
     gpu.append(ops.GPU_MARKS)
+    if plans():     # the slot this step used: its events are re-recorded two steps later, so read them now
+        torch.cuda.synchronize()
+        slot = plans()[0].slots[plans()[0].turn ^ 1]
+        raw.append({k: chain.elapsed_us(ref_raw, getattr(slot, k)) for k in ("ev_fork", "ev_ranks", "ev_tail")
+                    if k != "ev_tail" or slot.used})
+        for k, ev in chain.TIMING[-1].items():
+            try:
+                raw[-1][k] = chain.elapsed_us(ref_raw, ev)
+            except RuntimeError:
+                pass                      # a mark of a branch that did not run this step
+    else:
+        raw.append({})
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t_ref
 ops.HOST_TRACE = ops.GPU_MARKS = None
 print("ms/step %.3f" % (t_all / N * 1e3))
 acc = collections.OrderedDict()
-for (t0, tr), marks in list(zip(host, gpu))[5:]:
+for (t0, tr), marks, rw in list(zip(host, gpu, raw))[5:]:
     base = (t0 - t_ref) * 1e6
+    for label, t in rw.items():
+        acc.setdefault("GPU  chain " + label, []).append(t - base)
     for label, t in tr:
         acc.setdefault("host " + label, []).append((t - t_ref) * 1e6 - base)
     for label, ev in marks:

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vit-inductive-bias-distillation_amd"))
 import torch
 from basd_amd import trainer as T, capture
+from tools import stock_models as SM
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
@@ -15,13 +16,13 @@ ap.add_argument("--dtype", default="bf16")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-student = T.StockViT().to(dev)                      # DeiT-S
-teacher = T.make_teacher(T.StockResNet().to(dev), 224)
+student = SM.StockViT().to(dev)                      # DeiT-S
+teacher = SM.make_teacher(SM.StockResNet().to(dev), 224)
 cfg = SimpleNamespace(training=SimpleNamespace(label_smoothing=0.1, learning_rate=1e-3, weight_decay=0.05),
                       basd=SimpleNamespace(num_extraction_points=4), model=SimpleNamespace(num_classes=1000))
 torch.manual_seed(42)
 ac = torch.bfloat16 if args.dtype == "bf16" else None
-tr = T.Trainer(student, cfg, teacher, student_info=T.probe_model(student, 224), autocast_dtype=ac, mixup=True)
+tr = T.Trainer(student, cfg, teacher, student_info=SM.probe_model(student, 224), autocast_dtype=ac, mixup=True)
 g = torch.Generator().manual_seed(1)
 B = args.batch
 # images with per-image structure (a random colour cast + noise) so that the teacher features are not pure noise

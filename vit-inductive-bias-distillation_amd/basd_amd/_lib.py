@@ -93,6 +93,8 @@ SIGNATURES = {
     "basd_event_record": [vp, vp],
     "basd_event_synchronize": [vp],
     "basd_event_query": [vp],
+    "basd_event_create_timed": [vp],
+    "basd_event_elapsed_ms": [vp, vp, vp],
 }
 
 class ProcrustesArgs(C.Structure):
@@ -129,7 +131,8 @@ class SelectorChainArgs(C.Structure):
         + [(n, vp) for n in ("grams", "d", "e", "tau", "vh", "vals", "tri_work", "tri_work_s", "ranks", "host_mirror",
                              "student_status_mirror", "zv", "vecs", "u_rot", "sw", "cos", "sigma", "d_out", "k_arr",
                              "sw_index", "jflags", "main_stream", "chain_stream", "student_stream", "tail_stream",
-                             "ev_fork", "ev_student", "ev_ranks", "ev_tail", "ev_slot_free")]
+                             "ev_fork", "ev_student", "ev_ranks", "ev_tail", "ev_slot_free",
+                             "tm_proj", "tm_tgram", "tm_scol0", "tm_scol1", "tm_sgram", "tm_tri0", "tm_mid", "tm_spec")]
     )
 
 

@@ -18,10 +18,24 @@ from . import _lib, ops
 SPEC_MARGIN = 8            # eigenvectors computed beyond the previous step's largest rank (the rank may grow a little)
 
 
-def _event() -> int:
+TIMED_EVENTS = False        # diagnostics (tools/step_clock.py): the plans' events carry time stamps
+TM_NAMES = ("tm_proj", "tm_tgram", "tm_scol0", "tm_scol1", "tm_sgram", "tm_tri0", "tm_mid", "tm_spec")
+# measurement (bench.py): while a list, every queued step appends {name: timed event} of its launches, ev_ranks included
+# (created per step: the slots' own events are re-recorded two steps later)
+TIMING: list | None = None
+
+
+def _event(timed: bool | None = None) -> int:
     h = C.c_void_p()
-    _lib.call("basd_event_create", C.byref(h))
+    _lib.call("basd_event_create_timed" if (TIMED_EVENTS if timed is None else timed) else "basd_event_create",
+              C.byref(h))
     return h.value
+
+
+def elapsed_us(ev_from: int, ev_to: int) -> float:
+    ms = C.c_float()
+    _lib.call("basd_event_elapsed_ms", ev_from, ev_to, C.byref(ms))
+    return 1e3 * ms.value
 
 
 class _Slot:
@@ -138,7 +152,19 @@ class SelectorChainPlan:
         slot.d_out.record_stream(self.tail_stream)
         a.d_out = slot.d_out.data_ptr()
         slot.kmax = a.kmax = self.speculative_kmax()
+        marks = None
+        if TIMING is not None:
+            marks = {name: _event(True) for name in TM_NAMES}
+            for name, ev in marks.items():
+                setattr(a, name, ev)
+        elif a.tm_proj:
+            for name in TM_NAMES:
+                setattr(a, name, None)
         _lib.call("basd_selector_chain", C.addressof(a))
+        if marks is not None:
+            marks["ranks"] = _event(True)           # behind the factorisation + rank kernel, on the chain stream
+            _lib.call("basd_event_record", marks["ranks"], self.chain_stream.cuda_stream)
+            TIMING.append(marks)
         slot.used = slot.used or slot.kmax > 0
         slot.student_status_pending = self.mode != 0
         return slot

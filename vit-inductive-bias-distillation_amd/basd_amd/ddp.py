@@ -25,6 +25,59 @@ class FlatGradBucket:
                        for _ in range(max(1, int(slots)))]
         self._pending: list = [None] * len(self._slots)
         self._slot = 0
+        self._attached: list = []
+        self._avg_ok = self._probe_avg(device)
+
+    @staticmethod
+    def _probe_avg(device) -> bool:
+        """Whether the backend reduces with ``ReduceOp.AVG`` (RCCL does, gloo does not): decided ONCE, here, with a
+        one-element all-reduce that is waited for -- a rejection may only surface when the work is joined, which a
+        try / except around the hot path's async call would never see."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return False
+        if dist.get_backend() != "nccl":
+            return False
+        try:
+            probe = torch.full((1,), float(dist.get_rank() + 1), device=device, dtype=torch.float32)
+            dist.all_reduce(probe, op=dist.ReduceOp.AVG, async_op=True).wait()
+            world = dist.get_world_size()
+            return abs(float(probe.item()) - (world + 1) / 2.0) < 1e-6
+        except (RuntimeError, ValueError):
+            return False
+
+    def attach_grads(self, student_params: list[torch.nn.Parameter]) -> None:
+        """Make ``.grad`` of every student parameter and of every loss parameter a view into the (single) flat buffer:
+        autograd then accumulates straight into it and the optimizer reads the reduced values out of it -- no
+        per-parameter pack / unpack kernels.  Needs ``slots == 1`` and fp32 parameters on the buffer's device."""
+        assert len(self._slots) == 1, "gradient views need one buffer: the optimizer reads the gradients where they are reduced"
+        params = list(student_params) + self.loss_params
+        assert sum(p.numel() for p in student_params) == self.student_numel
+        self.buffer.zero_()
+        off = 0
+        self._attached = []
+        for p in params:
+            n = p.numel()
+            assert p.dtype == torch.float32 and p.device == self.buffer.device
+            view = self.buffer[off:off + n].view_as(p)
+            p.grad = view
+            self._attached.append((p, view))
+            off += n
+
+    def reattach_missing(self) -> int:
+        """After a backward: a parameter whose ``.grad`` is no longer its view (set to None by somebody, or replaced
+        instead of accumulated into) is copied back into the buffer and re-attached.  Returns how many needed it
+        (0 in the steady state: the tests assert that)."""
+        fixed = 0
+        for p, view in self._attached:
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            else:
+                continue
+            p.grad = view
+            fixed += 1
+        return fixed
 
     @property
     def buffer(self) -> torch.Tensor:
@@ -65,14 +118,10 @@ class FlatGradBucket:
         the work already on the current stream); ``wait`` / ``next_slot`` join it."""
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return
-        work = divide = None
-        if dist.get_backend() == "nccl" and getattr(self, "_avg_ok", True):
-            try:
-                work = dist.all_reduce(self.buffer, op=dist.ReduceOp.AVG, async_op=True)   # RCCL averages in the reduction
-                divide = False
-            except (RuntimeError, ValueError):                      # a build without ncclAvg: rejected before launch
-                self._avg_ok = False
-        if work is None:
+        if self._avg_ok:       # decided once by ``_probe_avg``
+            work = dist.all_reduce(self.buffer, op=dist.ReduceOp.AVG, async_op=True)       # RCCL averages in the reduction
+            divide = False
+        else:
             work = dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, async_op=True)       # gloo (CPU tests) has no AVG
             divide = True
         self._pending[self._slot] = (work, divide)

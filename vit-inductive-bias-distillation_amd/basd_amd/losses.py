@@ -1088,7 +1088,7 @@ class BASDLoss(nn.Module):
         loss and the Procrustes loss + unit gradients follow on the caller's stream, then the host waits for the
         teacher ranks and for nothing else (the reference reads them, and raises on rank 0, inside forward)."""
         sel = self.layer_selector
-        sel.finish_pending()                   # the previous step's deferred read-back, if that mode is on
+        previous, sel._pending_tail = sel._pending_tail, None      # a read-back the previous step deferred (that mode)
         main = torch.cuda.current_stream()
         xs = ops._check_common_layout([ops.as_supported(x) for x in students], "student token tensors")
         plan = self._chain_plan(xs, teachers, main)
@@ -1133,9 +1133,16 @@ class BASDLoss(nn.Module):
             comp["d_grass_sq"] = plan.finish_tail(slot, ranks)
 
         if self.sync_ranks:
+            if previous is not None:
+                previous()
             complete()
         else:
+            # deferred: this step's ranks are read by the next forward or by the first reader of ``subspace_ranks``;
+            # the PREVIOUS step's now, with this step already queued (its rank kernel finished long ago -- if not,
+            # this wait is the back-pressure that keeps the host at most one step ahead)
             sel._pending_tail = complete
+            if previous is not None:
+                previous()
         return total, ce_loss, geo_layers, mix
 
     # (no torch.compiler.disable wrapper: it costs ~40 us of host time per call on the step's critical path;

@@ -543,6 +543,82 @@ def _check_common_layout(tensors: list[torch.Tensor], what: str) -> list[torch.T
     return out
 
 
+class _ProcrustesPlan:
+    """Persistent scratch + a pre-filled ``BasdProcrustesArgs`` for one (shapes, layouts, options, stream) key.
+
+    Scratch (mixed teacher, fp64 Grams / factors, stacked cores, Jacobi flags, ...) is only alive inside the call's own
+    launches on ONE stream, so it is allocated once and reused by every step; what outlives the call -- the tensors kept
+    for the backward and the student gradients handed to autograd -- is allocated per call (two ``torch.empty``)."""
+
+    def __init__(self, E, L, B, n_s, d_s, n_t, d_t, H, A, has_cls, need_bwd, need_mix_grad, want_sweeps, want_dx,
+                 want_uw, dev):
+        import ctypes
+        self.E, self.L, self.B, self.n_s, self.d_s, self.n_t, self.d_t = E, L, B, n_s, d_s, n_t, d_t
+        n_a = A - (1 if has_cls else 0)
+        n = min(n_s, n_t)
+        self.n, self.n_a = n, n_a
+        self.tp = taps(n_t, n_s, dev) if n_t < n_s else None                 # student-side (transposed) taps
+        self.gt = taps(n_t, n_s, dev) if n_t > n_s else None                 # teacher-side gather taps
+        self.atp = taps(n_a, n_s, dev)
+        G = self.G = 1 if L == 1 else E          # softmax over one layer is exactly 1: the teacher side is shared
+        f32 = dict(device=dev, dtype=torch.float32)
+        slabs = (d_s + 31) // 32
+        EB, GB = E * B, G * B
+        self.need_bwd, self.need_mix_grad, self.want_dx, self.want_uw = need_bwd, need_mix_grad, want_dx, want_uw
+        # ---- kept sizes (fresh per call): omega, mu_s, a_prime, k_prime, terms (4, E, B), uw
+        self.kept_sizes = [G * B * n_s, E * B * d_s, EB * n * d_s, EB * n * n if need_bwd else 0, 4 * EB,
+                           (4 + 2 * E) if want_uw else 0]
+        # every piece starts on a 256-byte boundary, as separate allocations would (the kernels read them as float4)
+        self.kept_padded = [(c + 63) // 64 * 64 for c in self.kept_sizes]
+        self.kept_total = sum(self.kept_padded)
+        # ---- scratch
+        g_splits = 1
+        if GB < 1024 and d_t >= 512:           # few teacher Grams with a long feature axis: split the contraction
+            g_splits = max(1, min(1024 // GB, d_t // 256, 16))
+        self.g_splits = g_splits
+        self.g_all = torch.empty((EB + GB + (g_splits * GB if g_splits > 1 else 0), n, n), device=dev, dtype=torch.float64)
+        self.l_all = torch.empty((EB + GB, n, n), device=dev, dtype=torch.float64)
+        self.W = torch.empty((EB, n, 2 * n), **f32)        # memory == column-major (2n x n)
+        self.tc = torch.empty((G, B, n, d_t), **f32)
+        sizes = [GB * n, GB * d_t, EB * slabs, EB * n]
+        padded = [(c + 63) // 64 * 64 for c in sizes]
+        self.omega_t, self.mu_t, self.tr_part, self.sigma = (
+            piece[:c] for piece, c in zip(torch.split(torch.empty((sum(padded),), **f32), padded), sizes))
+        self.ints = torch.empty((_lib.query("basd_jacobi_workspace_ints", EB, MAX_SWEEPS) + EB,), device=dev,
+                                dtype=torch.int32)
+        self.sweeps = self.ints[-EB:] if want_sweeps else None
+        jac_bytes = _lib.query("basd_jacobi_twopass_workspace_bytes", n, EB, MAX_SWEEPS) if TWO_PASS_SVD else 0
+        if jac_bytes > TWO_PASS_LOG_LIMIT or (jac_bytes > (256 << 20)
+                                              and jac_bytes > torch.cuda.mem_get_info(dev)[0] // 2):
+            jac_bytes = 0       # very large batches / little free memory: the block solver needs no log
+        self.jac_ws = torch.empty((jac_bytes // 8 + 1,), device=dev, dtype=torch.int64) if jac_bytes > 0 else None
+        self.h = torch.empty((E, B, n, d_s), **f32) if want_dx else None
+        self.host_ptrs = (ctypes.c_void_p * E)()
+
+        a = self.args = _lib.ProcrustesArgs()
+        a.student_host_ptrs = ctypes.cast(self.host_ptrs, ctypes.c_void_p)
+        (a.E, a.L, a.G, a.B, a.n_s, a.n_t, a.d_s, a.d_t, a.H, a.A, a.has_cls, a.n_a, a.n, a.max_sweeps) = \
+            E, L, G, B, n_s, n_t, d_s, d_t, H, A, int(has_cls), n_a, n, MAX_SWEEPS
+        if self.atp:
+            a.atap0, a.atap1, a.alam = self.atp.tap0.data_ptr(), self.atp.tap1.data_ptr(), self.atp.lam.data_ptr()
+        if self.tp:
+            a.tap0, a.tap1, a.lam = self.tp.tap0.data_ptr(), self.tp.tap1.data_ptr(), self.tp.lam.data_ptr()
+            a.range0, a.range1 = self.tp.range0.data_ptr(), self.tp.range1.data_ptr()
+        if self.gt:
+            a.g0, a.g1, a.glam = self.gt.tap0.data_ptr(), self.gt.tap1.data_ptr(), self.gt.lam.data_ptr()
+        a.omega_t, a.mu_t, a.tc, a.tr_part = (self.omega_t.data_ptr(), self.mu_t.data_ptr(), self.tc.data_ptr(),
+                                              self.tr_part.data_ptr())
+        a.g_all, a.l_all, a.W = self.g_all.data_ptr(), self.l_all.data_ptr(), self.W.data_ptr()
+        a.sigma, a.jflags, a.sweeps = self.sigma.data_ptr(), self.ints.data_ptr(), _ptr(self.sweeps)
+        a.h = _ptr(self.h)
+        a.g_slabs = self.g_all[EB + GB:].data_ptr() if g_splits > 1 else None
+        a.g_splits = g_splits
+        a.jac_ws = _ptr(self.jac_ws)
+
+
+_PROCRUSTES_PLANS: dict = {}
+
+
 def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor], attns: list[torch.Tensor],
                        mix: torch.Tensor, has_cls: bool, *, need_backward: bool = True,
                        want_sweeps: bool = False, need_mix_grad: bool = False,
@@ -554,7 +630,8 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     (``ctx.dx``: (E, B, N_s, D_s) fp32).  ``uwso_ce`` (one fp32 on the device, the base loss): the UW-SO combination
     (combined.py:76-85) is computed inside the call as well -- ``ctx.uw`` = [w_ce, w_geo, total, geo, E x w_geo / E,
     E per-layer means] -- and ``ctx.dx`` are then the gradients of ``total`` for a unit upstream gradient.
-    Everything is queued by ONE library call (basd_procrustes_forward_fused)."""
+    Everything is queued by ONE library call (basd_procrustes_forward_fused) into a persistent, shape-keyed workspace
+    (``_ProcrustesPlan``): what the step's host time buys is two allocations and a handful of pointer updates."""
     import ctypes
     E, L = len(students), len(teachers)
     students = [as_supported(s) for s in students]
@@ -563,108 +640,75 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     teachers = _check_common_layout([as_supported(t) for t in teachers], "teacher token tensors")
     attns = _check_common_layout([as_supported(a) for a in attns], "teacher attention tensors")
     _require_cuda(*students, *teachers, *attns, mix)
-    dev = students[0].device
-    B, n_s, d_s = students[0].shape
-    _, n_t, d_t = teachers[0].shape
-    H, A = attns[0].shape[1], attns[0].shape[2]
-    n_a = A - (1 if has_cls else 0)
-    # Core grid: the coarser of the two token grids.  A coarser teacher (CNN feature maps) keeps its own
-    # grid and the interpolation is applied, transposed, to the student side; a finer teacher is resampled
-    # to the student grid while it is being mixed / centred.
-    n = min(n_s, n_t)
-    tp = taps(n_t, n_s, dev) if n_t < n_s else None                      # student-side (transposed) taps
-    gt = taps(n_t, n_s, dev) if n_t > n_s else None                      # teacher-side gather taps
-    atp = taps(n_a, n_s, dev)
-    mix = mix.contiguous().float()
-    shared = L == 1            # softmax over one layer is exactly 1: the teacher side is identical for all e
-    G = 1 if shared else E
-    f32 = dict(device=dev, dtype=torch.float32)
-    slabs = (d_s + 31) // 32
-    EB, GB = E * B, G * B
+    s0, t0, a0 = students[0], teachers[0], attns[0]
+    dev = s0.device
+    B, n_s, d_s = s0.shape
+    _, n_t, d_t = t0.shape
+    H, A = a0.shape[1], a0.shape[2]
     need_bwd = need_backward or grad_layers is not None
-    # kept for the backward / returned
-    omega = torch.empty((G, B, n_s), **f32)
-    mu_s = torch.empty((E, B, d_s), **f32)
-    a_prime = torch.empty((E, B, n, d_s), **f32)
-    k_prime = torch.empty((E, B, n, n), **f32) if need_bwd else None
-    terms = torch.empty((4, E, B), **f32)                                # tr_s, tr_t, nuc, loss_b
-    tc = torch.empty((G, B, n, d_t), **f32)
-    # teacher Gram: few matrices with a long feature axis -> split the contraction over several workgroups each
-    g_splits = 1
-    if GB < 1024 and d_t >= 512:
-        g_splits = max(1, min(1024 // GB, d_t // 256, 16))
-    g_all = torch.empty((EB + GB + (g_splits * GB if g_splits > 1 else 0), n, n), device=dev, dtype=torch.float64)
-    g_slabs = g_all[EB + GB:] if g_splits > 1 else None
-    g_all = g_all[:EB + GB]
-    l_all = torch.empty_like(g_all)
-    W = torch.empty((EB, n, 2 * n), **f32)      # memory == column-major (2n x n)
-    # transient fp32 scratch in one allocation
-    sizes = [GB * n, GB * d_t, EB * slabs, EB * n]
-    omega_t, mu_t, tr_part, sigma = torch.split(torch.empty((sum(sizes),), **f32), sizes)
-    ints = torch.empty((_lib.query("basd_jacobi_workspace_ints", EB, MAX_SWEEPS) + EB,), device=dev, dtype=torch.int32)
-    sweeps = None
-    if want_sweeps:
-        sweeps = ints[-EB:]
-        sweeps.zero_()
-    # cores whose 2n rows are past LDS while n rows fit: rotation log of the two-pass SVD (0 bytes: shape not covered)
-    jac_bytes = _lib.query("basd_jacobi_twopass_workspace_bytes", n, EB, MAX_SWEEPS) if TWO_PASS_SVD else 0
-    if jac_bytes > TWO_PASS_LOG_LIMIT or (jac_bytes > (256 << 20)
-                                          and jac_bytes > torch.cuda.mem_get_info(dev)[0] // 2):
-        jac_bytes = 0       # very large batches / little free memory: the block solver needs no log
-    jac_ws = torch.empty((jac_bytes // 8 + 1,), device=dev, dtype=torch.int64) if jac_bytes > 0 else None
-    raw = torch.empty((G, B, n_a), **f32) if need_mix_grad else None
-    h = dx = uw = None
+    want_dx = grad_layers is not None or uwso_ce is not None
+    stream = _stream()
+    # mixing-weight gradients read the call's scratch in backward (W, sigma, tc, Grams): those calls get private scratch
+    key = (E, L, B, n_s, d_s, n_t, d_t, H, A, bool(has_cls), need_bwd, need_mix_grad, want_sweeps, want_dx,
+           uwso_ce is not None, dev, stream, TWO_PASS_SVD)
+    plan = None if need_mix_grad else _PROCRUSTES_PLANS.get(key)
+    if plan is None:
+        plan = _ProcrustesPlan(E, L, B, n_s, d_s, n_t, d_t, H, A, has_cls, need_bwd, need_mix_grad, want_sweeps, want_dx,
+                               uwso_ce is not None, dev)
+        if not need_mix_grad:
+            if len(_PROCRUSTES_PLANS) >= 8:
+                torch.cuda.synchronize(dev)
+                _PROCRUSTES_PLANS.clear()
+            _PROCRUSTES_PLANS[key] = plan
+    n, n_a, G = plan.n, plan.n_a, plan.G
+    EB = E * B
+    mix = mix.contiguous().float()
+    kept = torch.empty((plan.kept_total,), device=dev, dtype=torch.float32)
+    omega, mu_s, a_prime, k_prime, terms, uw = (piece[:c] for piece, c in
+                                                zip(torch.split(kept, plan.kept_padded), plan.kept_sizes))
+    omega, mu_s = omega.view(G, B, n_s), mu_s.view(E, B, d_s)
+    a_prime = a_prime.view(E, B, n, d_s)
+    k_prime = k_prime.view(E, B, n, n) if need_bwd else None
+    terms = terms.view(4, E, B)
+    uw = uw if uwso_ce is not None else None
+    raw = torch.empty((G, B, n_a), device=dev, dtype=torch.float32) if need_mix_grad else None
+    dx = torch.empty((E, B, n_s, d_s), device=dev, dtype=torch.float32) if want_dx else None
+    if plan.sweeps is not None:
+        plan.sweeps.zero_()
     if uwso_ce is not None:
         assert uwso_ce.dtype == torch.float32 and uwso_ce.numel() == 1 and uwso_ce.device == dev
-        uw = torch.empty((4 + 2 * E,), **f32)
-    if grad_layers is not None or uw is not None:
-        h = torch.empty((E, B, n, d_s), **f32)
-        dx = torch.empty((E, B, n_s, d_s), **f32)
-        if grad_layers is not None:
-            grad_layers = grad_layers.contiguous().float()
+    if grad_layers is not None:
+        grad_layers = grad_layers.contiguous().float()
 
-    args = _lib.ProcrustesArgs()
-    host_ptrs = (ctypes.c_void_p * E)(*[s.data_ptr() for s in students])
+    args = plan.args
+    for e, s in enumerate(students):
+        plan.host_ptrs[e] = s.data_ptr()
     args.student_ptrs = _ptr_table(students).data_ptr()
-    args.student_host_ptrs = ctypes.cast(host_ptrs, ctypes.c_void_p)
-    args.s_dtype, args.s_sb, args.s_sn = _dtype_code(students[0]), students[0].stride(0), students[0].stride(1)
+    args.s_dtype, args.s_sb, args.s_sn = _dtype_code(s0), s0.stride(0), s0.stride(1)
     args.s_aligned = int(all(s.data_ptr() % 16 == 0 for s in students))
     args.tok_ptrs = _ptr_table(teachers).data_ptr()
-    args.t_dtype = _dtype_code(teachers[0])
-    args.t_sb, args.t_sn, args.t_sd = teachers[0].stride()
+    args.t_dtype = _dtype_code(t0)
+    args.t_sb, args.t_sn, args.t_sd = t0.stride()
     args.attn_ptrs = _ptr_table(attns).data_ptr()
-    args.a_dtype = _dtype_code(attns[0])
-    args.a_sb, args.a_sh, args.a_sq, args.a_sk = attns[0].stride()
+    args.a_dtype = _dtype_code(a0)
+    args.a_sb, args.a_sh, args.a_sq, args.a_sk = a0.stride()
     args.mix = mix.data_ptr()
-    (args.E, args.L, args.G, args.B, args.n_s, args.n_t, args.d_s, args.d_t, args.H, args.A, args.has_cls, args.n_a,
-     args.n, args.max_sweeps) = E, L, G, B, n_s, n_t, d_s, d_t, H, A, int(has_cls), n_a, n, MAX_SWEEPS
-    if atp:
-        args.atap0, args.atap1, args.alam = atp.tap0.data_ptr(), atp.tap1.data_ptr(), atp.lam.data_ptr()
-    if tp:
-        args.tap0, args.tap1, args.lam = tp.tap0.data_ptr(), tp.tap1.data_ptr(), tp.lam.data_ptr()
-        args.range0, args.range1 = tp.range0.data_ptr(), tp.range1.data_ptr()
-    if gt:
-        args.g0, args.g1, args.glam = gt.tap0.data_ptr(), gt.tap1.data_ptr(), gt.lam.data_ptr()
-    args.omega, args.omega_t, args.raw = omega.data_ptr(), omega_t.data_ptr(), _ptr(raw)
-    args.mu_t, args.tc, args.mu_s, args.tr_part = mu_t.data_ptr(), tc.data_ptr(), mu_s.data_ptr(), tr_part.data_ptr()
+    args.omega, args.raw, args.mu_s = omega.data_ptr(), _ptr(raw), mu_s.data_ptr()
     args.tr_s, args.tr_t, args.nuc, args.loss_b = (terms[i].data_ptr() for i in range(4))
-    args.a_prime, args.g_all, args.l_all, args.W = a_prime.data_ptr(), g_all.data_ptr(), l_all.data_ptr(), W.data_ptr()
-    args.sigma, args.jflags, args.sweeps, args.k_prime = sigma.data_ptr(), ints.data_ptr(), _ptr(sweeps), _ptr(k_prime)
-    args.h, args.dx, args.grad_layers = _ptr(h), _ptr(dx), _ptr(grad_layers)
-    args.g_slabs, args.g_splits = _ptr(g_slabs), g_splits
+    args.a_prime, args.k_prime = a_prime.data_ptr(), _ptr(k_prime)
+    args.dx, args.grad_layers = _ptr(dx), _ptr(grad_layers)
     args.uw_ce, args.uw_out = _ptr(uwso_ce), _ptr(uw)
-    args.jac_ws = _ptr(jac_ws)
     gpu_mark("procrustes_begin")
-    _lib.call("basd_procrustes_forward_fused", ctypes.addressof(args), _stream())
+    _lib.call("basd_procrustes_forward_fused", ctypes.addressof(args), stream)
     gpu_mark("procrustes_end")
-    del host_ptrs
 
     mixgrad = None
     if need_mix_grad:
-        l_a, g_b = l_all[:EB], g_all[EB:]
-        mixgrad = dict(raw=raw, tc=tc, l_a=l_a, g_b=g_b, W=W, sigma=sigma, omega_e=omega, teachers=teachers,
-                       attns=attns, tok_tab=_ptr_table(teachers), att_tab=_ptr_table(attns), has_cls=has_cls, n_a=n_a,
-                       n=n, n_s=n_s, gather=gt, student_taps=tp, attn_taps=atp)
+        l_a, g_b = plan.l_all[:EB], plan.g_all[EB:EB + G * B]
+        mixgrad = dict(raw=raw, tc=plan.tc, l_a=l_a, g_b=g_b, W=plan.W, sigma=plan.sigma, omega_e=omega,
+                       teachers=teachers, attns=attns, tok_tab=_ptr_table(teachers), att_tab=_ptr_table(attns),
+                       has_cls=has_cls, n_a=n_a, n=n, n_s=n_s, gather=plan.gt, student_taps=plan.tp, attn_taps=plan.atp)
+    sweeps = plan.sweeps.clone() if plan.sweeps is not None else None
     return ProcrustesContext(omega, mu_s, a_prime, k_prime, terms[0], terms[1], terms[2], terms[3], sweeps, mixgrad,
                              dx, uw)
 

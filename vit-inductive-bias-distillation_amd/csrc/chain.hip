@@ -46,6 +46,11 @@ __global__ void chain_k_arr_kernel(const int* __restrict__ ranks, int L, int ite
         hipError_t e_ = (call);                 \
         if (e_ != hipSuccess) return (int)e_;   \
     } while (0)
+// optional measurement event (nullable)
+#define BASD_MARK(ev, stream)                                         \
+    do {                                                              \
+        if (ev) BASD_HIP(hipEventRecord((hipEvent_t)(ev), (stream))); \
+    } while (0)
 
 extern "C" {
 
@@ -57,6 +62,17 @@ int basd_event_record(void* ev, hipStream_t stream) {
 int basd_event_synchronize(void* ev) {
     BASD_CHECK_ARG(ev);
     BASD_HIP(hipEventSynchronize((hipEvent_t)ev));
+    return BASD_OK;
+}
+// diagnostics (tools/step_clock.py): events that carry a time stamp, and the time between two of them
+int basd_event_create_timed(void** out) {
+    BASD_CHECK_ARG(out);
+    BASD_HIP(hipEventCreateWithFlags((hipEvent_t*)out, hipEventDefault));
+    return BASD_OK;
+}
+int basd_event_elapsed_ms(void* from, void* to, float* ms_out) {
+    BASD_CHECK_ARG(from && to && ms_out);
+    BASD_HIP(hipEventElapsedTime(ms_out, (hipEvent_t)from, (hipEvent_t)to));
     return BASD_OK;
 }
 // 1 when everything recorded before the event has completed, 0 when not yet
@@ -89,6 +105,7 @@ int basd_selector_chain_tail(const BasdSelectorChain* a, int kmax, int exact_k) 
     const float* vz = a->vh + (long)L * nn;
     float* lam = a->vals + (long)L * n;
     BASD_TRY(basd_tridiag_eigenvalues(dz, ez, n, L + E, lam, st));
+    BASD_MARK(a->tm_spec, st);
     // rows of vecs: (L + E, kmax, n) -- teacher bases first, then Vt_s[:kmax] of every student layer
     BASD_TRY(basd_tridiag_eigenvectors(dz, ez, tz, vz, lam, n, kmax, L + E, a->zv, a->vecs, kmax, st));
     basd::chain_sw_kernel<<<L, 256, 0, st>>>(lam, n, kmax, a->sw);
@@ -144,16 +161,21 @@ int basd_selector_chain(const BasdSelectorChain* a) {
         BASD_TRY(basd_gemm_nt(a->teacher_host_ptrs[l], (int)a->t_dtype, a->t_sb, a->t_sn, a->t_sd, n_t, 0, a->proj_t, d_t,
                               0, (int)M_t, n, d_t, 1, a->z + (long)l * M_t * n, n, M_t * n, 1.f, nullptr, 0.f,
                               a->z_sums + (long)l * tiles * n, nullptr, cs));
+    BASD_MARK(a->tm_proj, cs);
     BASD_TRY(basd_syrk_multi(a->z_ptrs, BASD_DTYPE_F32, 0, n, 1, 1 << 30, (int)M_t, n, 2 * L, nullptr, a->t_scales,
                              (int)a->t_splits, a->t_slabs, a->grams, nn, 1, a->z_sums, tiles, L, cs));
+    BASD_MARK(a->tm_tgram, cs);
 
     auto student_grams = [&](hipStream_t st) -> int {
         // centred Grams of the E student layers (:88-91; proj_s folded into the principal angles)
+        BASD_MARK(a->tm_scol0, st);
         BASD_TRY(basd_colmean_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, a->s_sd, n_s, (int)M_s, n, E,
                                     (int)a->s_parts, a->s_partial, a->s_means, (int)a->s_vec_ok, st));
+        BASD_MARK(a->tm_scol1, st);
         BASD_TRY(basd_syrk_multi(a->student_ptrs, (int)a->s_dtype, a->s_sb, a->s_sn, a->s_sd, n_s, (int)M_s, n, E,
                                  a->s_means, nullptr, (int)a->s_splits, a->s_slabs, a->grams + 2L * L * nn, nn,
                                  (int)a->s_vec_ok, nullptr, 0, 0, st));
+        BASD_MARK(a->tm_sgram, st);
         return BASD_OK;
     };
 
@@ -164,14 +186,16 @@ int basd_selector_chain(const BasdSelectorChain* a) {
             BASD_HIP(hipEventRecord((hipEvent_t)a->ev_student, ss));
             BASD_HIP(hipStreamWaitEvent(cs, (hipEvent_t)a->ev_student, 0));
         }
+        BASD_MARK(a->tm_tri0, cs);
         BASD_TRY(basd_tridiag_ranked(a->grams, nn, n, 2 * L + E, a->d, a->e, a->tau, a->vh, a->tri_work, L, a->mp_factor,
-                                     (int)a->rank_cap, a->ranks, a->host_mirror, nullptr, cs));
+                                     (int)a->rank_cap, a->ranks, a->host_mirror, a->tm_mid, cs));
         BASD_HIP(hipEventRecord((hipEvent_t)a->ev_ranks, cs));
     } else {
         // teacher matrices first (the host waits for their ranks); the student side on its own stream, in mode 1 held
         // back until the ranks are out (its Gram launch is the largest MFMA launch of the step)
+        BASD_MARK(a->tm_tri0, cs);
         BASD_TRY(basd_tridiag_ranked(a->grams, nn, n, 2 * L, a->d, a->e, a->tau, a->vh, a->tri_work, L, a->mp_factor,
-                                     (int)a->rank_cap, a->ranks, a->host_mirror, nullptr, cs));
+                                     (int)a->rank_cap, a->ranks, a->host_mirror, a->tm_mid, cs));
         BASD_HIP(hipEventRecord((hipEvent_t)a->ev_ranks, cs));
         BASD_CHECK_ARG(a->tri_work_s != nullptr && ss != cs);
         if (mode == 1) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_ranks, 0));

@@ -923,6 +923,386 @@ __global__ void __launch_bounds__(512) tridiag_tail2_kernel(float* __restrict__ 
 #undef TAIL_PAIR
 #undef TAIL_CAP
 // ---------------------------------------------------------------------------
+// tridiag_packed_kernel: the WHOLE factorisation of one matrix of order 256 < n <= 384 in the registers of ONE CU -- no
+// shared stage, no members, nothing spins, nothing of the matrix is re-read from L2 -- by keeping only the UPPER
+// TRIANGLE (295 KB of the CU's 512 KB of VGPRs; the full 384^2 matrix is 590 KB).
+//
+// Why: the two-stage layout above (steps [0, n - 256) shared by up to 16 workgroups through L2 granules, then
+// tridiag_tail2_kernel) takes 0.97 ms alone at n = 384 but 1.3-1.4 ms inside a training step: its 16-96 spinning
+// workgroups share their CUs' issue slots, LDS and the L2 with the Procrustes kernels of the caller's stream, and cost
+// THOSE 0.4 ms as well (round-3 step clock).  A workgroup that owns its CU's register file shares nothing.
+//
+// Layout (8 waves x 64 lanes): wave w owns the rows r = w + 8 i (i < 48), lane l the columns c = l + 64 k (k < 6); an
+// element a[r][c] with c >= r lives in (w, l).  Rows are kept in PAIRS P (rows i = 2P, 2P + 1: r_a = w + 16 P,
+// r_b = r_a + 8) as packed registers (a[r_a][c], a[r_b][c]); row pair P needs the column chunks k >= P >> 2 (both rows
+// of a pair start in the same chunk): 4 (6 + 5 + 4 + 3 + 2 + 1) = 84 packed registers = 168 VGPRs per lane.  In a
+// pair's first ("boundary") chunk the lanes left of the diagonal are padding (kept 0) and the DIAGONAL element is
+// stored HALVED: every stored element then contributes to both y_c += a u_r and y_r += a u_c, and the diagonal's two
+// half contributions add up to a[r][r] u_r (halving and doubling are exact).
+//
+// A step (same algorithm and update order as tridiag_tail2_kernel, run on the upper triangle):
+//   pass      per row pair and chunk: a -= m (v_r w_c + w_r v_c)  [pending update of the previous step; m = the
+//             boundary mask 1 / 0.5 / 0 folded into the ROW operands], acc_c += a u_r (per-lane, per column: no
+//             cross-lane sum), t_r += a u_c (per row: summed across the 64 lanes of the wave afterwards).  All four
+//             products are v_pk_fma_f32 over the row pair; a wave-uniform operand pair (v_a, v_b) is used as is, a
+//             per-lane column operand is broadcast from one half of a register pair with op_sel.
+//   row sums  the 8 partials t of a batch of 4 row pairs are reduce-scattered across the wave: permlane32_swap +
+//             packed add, permlane16_swap + packed add, then 4 DPP steps inside a row of 16 lanes -- 17 instructions per
+//             8 matrix rows instead of 8 x 6.
+//   capture   the wave that owns row r0 = j + 1 copies it out (column form): the next reflector is built from it.
+//   A         barrier; wave 0: p = tau (sum over waves of acc + t), gamma, w, next pivot row, its norm, next reflector
+//             (one wave's scalar chain, wave-level sums only), publishes the operands of the next pass;   B  barrier.
+// The pass starts at the first batch of 4 row pairs that still has a live row (rows < r0 are finished: their u_r is
+// 0, so whatever the pass does to them is never read).
+// ---------------------------------------------------------------------------
+constexpr int PK_WAVES = 8, PK_NMAX = 384, PK_RPW = PK_NMAX / PK_WAVES, PK_PAIRS = PK_RPW / 2, PK_CH = PK_NMAX / 64;
+__host__ __device__ constexpr int pk_boff(int kb) { return 4 * (kb * PK_CH - kb * (kb - 1) / 2); }   // 0, 24, 44, 60, 72, 80
+__host__ __device__ constexpr int pk_idx(int P, int k) { return pk_boff(P >> 2) + (P & 3) * (PK_CH - (P >> 2)) + (k - (P >> 2)); }
+static_assert(pk_boff(6) == 84, "84 packed registers");
+
+template <int H>
+__device__ __forceinline__ void pk_fma_bc(tri_f2& acc, tri_f2 a, tri_f2 b) {      // acc += a * b[H] (b's half broadcast)
+    if constexpr (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pk_fma(tri_f2& acc, tri_f2 a, tri_f2 b) {          // acc += a * b
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ tri_f2 pk_mul(tri_f2 a, tri_f2 b) {
+    tri_f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ tri_f2 pk_add(tri_f2 a, tri_f2 b) {
+    tri_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (x, y) partial sums of two values each: x's lower / y's lower halves... one level of a reduce-scatter across the wave.
+// After the call lanes [0, 32) hold lo's sum over {l, l + 32}, lanes [32, 64) hi's -- for both components.
+__device__ __forceinline__ tri_f2 pk_fold32(tri_f2 lo, tri_f2 hi) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
+    return pk_add(tri_f2{__uint_as_float(a[0]), __uint_as_float(b[0])}, tri_f2{__uint_as_float(a[1]), __uint_as_float(b[1])});
+}
+// the same one level down: even rows of 16 lanes end with lo's sum over {l, l + 16}, odd rows with hi's
+__device__ __forceinline__ tri_f2 pk_fold16(tri_f2 lo, tri_f2 hi) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
+    return pk_add(tri_f2{__uint_as_float(a[0]), __uint_as_float(b[0])}, tri_f2{__uint_as_float(a[1]), __uint_as_float(b[1])});
+}
+
+#ifdef BASD_TAIL_DBG
+#define PK_STAMP(slot) do { if (z == 0 && lane == 0 && jl < 384) g_tail_dbg[(jl * 8 + (slot)) * 8 + wave] = clock64(); } while (0)
+#else
+#define PK_STAMP(slot) do { } while (0)
+#endif
+// x[q] of six wave-uniform values by a wave-uniform q in 0..5: scalar selects (no branches, no VALU)
+__device__ __forceinline__ float uniform_select6(float t0, float t1, float t2, float t3, float t4, float t5, int q) {
+    int r;
+    asm("s_cmp_eq_u32 %7, 1\n\t"
+        "s_cselect_b32 %0, %2, %1\n\t"
+        "s_cmp_eq_u32 %7, 2\n\t"
+        "s_cselect_b32 %0, %3, %0\n\t"
+        "s_cmp_eq_u32 %7, 3\n\t"
+        "s_cselect_b32 %0, %4, %0\n\t"
+        "s_cmp_eq_u32 %7, 4\n\t"
+        "s_cselect_b32 %0, %5, %0\n\t"
+        "s_cmp_eq_u32 %7, 5\n\t"
+        "s_cselect_b32 %0, %6, %0"
+        : "=&s"(r)
+        : "s"(__float_as_int(t0)), "s"(__float_as_int(t1)), "s"(__float_as_int(t2)), "s"(__float_as_int(t3)),
+          "s"(__float_as_int(t4)), "s"(__float_as_int(t5)), "s"(q)
+        : "scc");
+    return __int_as_float(r);
+}
+
+// Lane <-> column map inside a chunk of 64 columns: lane l holds column 64 k + pi(l), pi(l) = 8 (l & 7) + (l >> 3) (an
+// involution).  As a ROW, that column belongs to wave l >> 3, row index i = 8 k + (l & 7): batch k, slot l & 7 -- so the
+// eight lanes l & 7 = 0..7 of one 8-lane group hold, chunk by chunk, exactly the eight rows of one batch of one wave, and
+// wave 0 publishes a step's row operands with 18 ds_write_b32 at immediate offsets from ONE per-lane base address.
+__device__ __forceinline__ int pk_pi(int l) { return 8 * (l & 7) + (l >> 3); }
+
+// one row pair of the pass (chunks K >= P >> 2); row operands of the pair: VAB = (v_a, v_b), WAB = (w_a, w_b), U2 = (u_a, u_b)
+#define PK_CHUNK(P, K, VAB, WAB, U2)                                               \
+    if constexpr ((K) >= ((P) >> 2) && (K) < PK_CH) {                              \
+        tri_f2 a_ = A2[pk_idx(P, K)];                                              \
+        pk_fma_bc<(K) & 1>(a_, VAB, NW[(K) >> 1]);                                 \
+        pk_fma_bc<(K) & 1>(a_, WAB, NV[(K) >> 1]);                                 \
+        A2[pk_idx(P, K)] = a_;                                                     \
+        pk_fma(acc2[K], a_, U2);                                                   \
+        pk_fma_bc<(K) & 1>(t2[(P) & 3], a_, UC[(K) >> 1]);                         \
+    }
+#define PK_PAIR(P, VAB, WAB, U2)                                                   \
+    {                                                                              \
+        const tri_f2 vm_ = pk_mul(VAB, MK2[(P) & 3]), wm_ = pk_mul(WAB, MK2[(P) & 3]); \
+        constexpr int KB_ = (P) >> 2;                                              \
+        PK_CHUNK(P, KB_, vm_, wm_, U2)                                             \
+        PK_CHUNK(P, KB_ + 1, VAB, WAB, U2)                                         \
+        PK_CHUNK(P, KB_ + 2, VAB, WAB, U2)                                         \
+        PK_CHUNK(P, KB_ + 3, VAB, WAB, U2)                                         \
+        PK_CHUNK(P, KB_ + 4, VAB, WAB, U2)                                         \
+        PK_CHUNK(P, KB_ + 5, VAB, WAB, U2)                                         \
+    }
+// one batch of 4 row pairs (rows i in [8 KB, 8 KB + 8) of every wave) and the cross-lane sums of their 8 partials;
+// the batch's row operands are 24 consecutive floats of the table: v x 8, w x 8, u x 8 (slot = i & 7)
+#define PK_BATCH(KB)                                                               \
+    case KB: {                                                                     \
+        const tri_f32x4* ob_ = (const tri_f32x4*)(optab_w + 24 * (KB));            \
+        tri_f2 t2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};           \
+        {                                                                          \
+            const tri_f32x4 v0_ = ob_[0], w0_ = ob_[2], u0_ = ob_[4];              \
+            PK_PAIR(4 * (KB) + 0, (tri_f2{v0_.x, v0_.y}), (tri_f2{w0_.x, w0_.y}), (tri_f2{u0_.x, u0_.y})) \
+            PK_PAIR(4 * (KB) + 1, (tri_f2{v0_.z, v0_.w}), (tri_f2{w0_.z, w0_.w}), (tri_f2{u0_.z, u0_.w})) \
+        }                                                                          \
+        {                                                                          \
+            const tri_f32x4 v1_ = ob_[1], w1_ = ob_[3], u1_ = ob_[5];              \
+            PK_PAIR(4 * (KB) + 2, (tri_f2{v1_.x, v1_.y}), (tri_f2{w1_.x, w1_.y}), (tri_f2{u1_.x, u1_.y})) \
+            PK_PAIR(4 * (KB) + 3, (tri_f2{v1_.z, v1_.w}), (tri_f2{w1_.z, w1_.w}), (tri_f2{u1_.z, u1_.w})) \
+        }                                                                          \
+        tri_f2 s_ = pk_fold16(pk_fold32(t2[0], t2[1]), pk_fold32(t2[2], t2[3]));   \
+        s_.x = row16_allsum(s_.x);                                                 \
+        s_.y = row16_allsum(s_.y);                                                 \
+        /* row of 16 lanes 0: pair 0, 1: pair 2, 2: pair 1, 3: pair 3 */          \
+        if ((lane & 15) == 0) *(tri_f2*)(yrow_q + 8 * (KB)) = s_;                  \
+    }                                                                              \
+    [[fallthrough]];
+#define PK_CAP(P)                                                                  \
+    case P: {                                                                      \
+        _Pragma("unroll") for (int k = (P) >> 2; k < PK_CH; ++k) {                 \
+            const tri_f2 a_ = A2[pk_idx(P, k)];                                    \
+            float x_ = half ? a_.y : a_.x;                                         \
+            if (k == ((P) >> 2)) x_ *= capfix;                                     \
+            cap[k * 64 + lane] = x_;                                               \
+        }                                                                          \
+    } break;
+
+__global__ void __launch_bounds__(64 * PK_WAVES) tridiag_packed_kernel(float* __restrict__ A, long a_batch_stride, int n,
+                                                                       float* __restrict__ d, float* __restrict__ e,
+                                                                       float* __restrict__ tau_out,
+                                                                       float* __restrict__ Vh, MpRankOut rk) {
+    constexpr int WAVES = PK_WAVES, CH = PK_CH;
+    __builtin_amdgcn_s_setprio(3);
+    // row operands of the pass: [wave][batch kb][v x 8 | w x 8 | u x 8], slot = i & 7 of row w + 8 i, i = 8 kb + slot
+    __shared__ __attribute__((aligned(16))) float optab[WAVES][CH][24];
+    // column operands per lane (c = 64 k + pi(l)): u[6], -v[6], -w[6], 2 pad: five b128
+    __shared__ __attribute__((aligned(16))) float colf[64][20];
+    __shared__ __attribute__((aligned(16))) float part[WAVES][64][8];        // per-wave column partials (6 of 8 used)
+    __shared__ __attribute__((aligned(16))) float yrows[WAVES][PK_RPW];      // cross-lane row sums of row w + 8 i
+    __shared__ float cap[PK_NMAX];                    // the captured pivot row, by (chunk, lane)
+    __shared__ float dloc[PK_NMAX], eloc[PK_NMAX], tloc[PK_NMAX];
+    const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = pk_pi(lane);                       // my column inside every chunk
+    float* Az = A + (long)z * a_batch_stride;
+    float* Vz = Vh + (long)z * n * n;
+    const float* const optab_w = &optab[wave][0][0];
+    // where the lane that ends a batch's row reduction in row-of-16 rho writes its pair q = [0, 2, 1, 3][rho]
+    float* const yrow_q = &yrows[wave][0] + 2 * (((lane >> 5) & 1) | ((lane >> 3) & 2));
+    // where wave 0 publishes (u, v, w) of my columns as row operands: wave l >> 3, slot l & 7; per chunk + 24 floats
+    float* const pub = &optab[lane >> 3][0][0] + (lane & 7);
+    // where the last wave gathers u in natural column order c = lane + 64 k for the reflector row: row c is wave
+    // c & 7 = lane & 7, batch k, slot (c >> 3) & 7 = lane >> 3
+    const float* const ugather = &optab[lane & 7][0][0] + 16 + (lane >> 3);
+
+    // ---- the upper triangle, zero padded to 384, diagonal halved
+    tri_f2 A2[84];
+#pragma unroll
+    for (int P = 0; P < PK_PAIRS; ++P) {
+        const int ra = wave + 16 * P, rb = ra + 8;
+#pragma unroll
+        for (int k = P >> 2; k < CH; ++k) {
+            const int c = pl + 64 * k;
+            float xa = 0.f, xb = 0.f;
+            if (c < n) {
+                if (ra < n && c >= ra) xa = Az[(long)ra * n + c] * (c == ra ? 0.5f : 1.f);
+                if (rb < n && c >= rb) xb = Az[(long)rb * n + c] * (c == rb ? 0.5f : 1.f);
+            }
+            A2[pk_idx(P, k)] = tri_f2{xa, xb};
+        }
+    }
+    // boundary masks of the pairs P & 3 = q: rows i & 7 = 2 q, 2 q + 1 sit at column wave + 8 (i & 7) of their chunk
+    tri_f2 MK2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ta = wave + 16 * q, tb = ta + 8;
+        MK2[q] = tri_f2{pl > ta ? 1.f : (pl == ta ? 0.5f : 0.f), pl > tb ? 1.f : (pl == tb ? 0.5f : 0.f)};
+    }
+
+    float tau = 0.f;              // wave 0: tau of the current step
+    // column-form entry of column c (wave-uniform), broadcast: lane pi(c & 63), chunk c >> 6
+    auto pick = [&](const float (&x)[CH], int c) {
+        const int l = pk_pi(c & 63);
+        return uniform_select6(lane_bcast(x[0], l), lane_bcast(x[1], l), lane_bcast(x[2], l), lane_bcast(x[3], l),
+                               lane_bcast(x[4], l), lane_bcast(x[5], l), c >> 6);
+    };
+    // wave 0: reflector of step jl from cn[] (row jl of the current matrix, column form; dnew = its diagonal entry),
+    // then the operands of the next pass: u = the new reflector, v = uc (the old one), w = wn
+    auto next_reflector = [&](int jl, bool last, const float (&cn)[CH], const float (&uc)[CH], const float (&wn)[CH],
+                              float dnew) {
+        const int r0 = jl + 1;
+        float part2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) part2 = (pl + 64 * k > r0) ? fmaf(cn[k], cn[k], part2) : part2;
+        const float alpha = pick(cn, r0 < PK_NMAX ? r0 : PK_NMAX - 1);
+        const float xn2 = wave_sum(part2);
+        const bool live = !last && xn2 > 0.f;
+        const float beta = live ? -copysignf(__builtin_amdgcn_sqrtf(fmaf(alpha, alpha, xn2)), alpha) : (last ? 0.f : alpha);
+        tau = live ? (beta - alpha) * __builtin_amdgcn_rcpf(beta) : 0.f;
+        const float scal = live ? __builtin_amdgcn_rcpf(alpha - beta) : 0.f;
+        float un[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = pl + 64 * k;
+            un[k] = last ? 0.f : (c < r0 ? 0.f : (c == r0 ? 1.f : cn[k] * scal));
+            pub[24 * k] = uc[k];
+            pub[24 * k + 8] = wn[k];
+            pub[24 * k + 16] = un[k];
+        }
+        tri_f32x4* cf = (tri_f32x4*)&colf[lane][0];
+        cf[0] = tri_f32x4{un[0], un[1], un[2], un[3]};
+        cf[1] = tri_f32x4{un[4], un[5], -uc[0], -uc[1]};
+        cf[2] = tri_f32x4{-uc[2], -uc[3], -uc[4], -uc[5]};
+        cf[3] = tri_f32x4{-wn[0], -wn[1], -wn[2], -wn[3]};
+        cf[4] = tri_f32x4{-wn[4], -wn[5], 0.f, 0.f};
+        if (lane == 0) {
+            dloc[jl] = dnew;
+            eloc[jl] = beta;
+            tloc[jl] = tau;
+        }
+    };
+    // waves 1..6, behind barrier B: reflector row of step jl from the published u, natural column order, one chunk of
+    // 64 columns per wave (one LDS read + one store each: nobody starts the next pass late)
+    auto store_reflector = [&](int jl) {
+        const int k = wave - 1;
+        if (k >= 0 && k < CH && lane + 64 * k < n)
+            Vz[(long)jl * n + lane + 64 * k] = ugather[24 * k];
+    };
+    if (wave == 0) {
+        float cn[CH], zero[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            cn[k] = A2[pk_idx(0, k)].x * ((k == 0 && pl == 0) ? 2.f : 1.f);
+            zero[k] = 0.f;
+        }
+        next_reflector(0, n <= 1, cn, zero, zero, pick(cn, 0));
+    }
+    lds_barrier();
+    store_reflector(0);
+
+    for (int jl = 0; jl < n - 1; ++jl) {
+        const int r0 = jl + 1;
+        // ---- the pass
+        PK_STAMP(0);
+        tri_f2 NV[3], NW[3], UC[3], acc2[CH];
+        {
+            const tri_f32x4* cf = (const tri_f32x4*)&colf[lane][0];
+            const tri_f32x4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4];   // u0-3 | u4,u5,-v0,-v1 | -v2-5 | -w0-3 | -w4,-w5
+            UC[0] = tri_f2{c0.x, c0.y}; UC[1] = tri_f2{c0.z, c0.w}; UC[2] = tri_f2{c1.x, c1.y};
+            NV[0] = tri_f2{c1.z, c1.w}; NV[1] = tri_f2{c2.x, c2.y}; NV[2] = tri_f2{c2.z, c2.w};
+            NW[0] = tri_f2{c3.x, c3.y}; NW[1] = tri_f2{c3.z, c3.w}; NW[2] = tri_f2{c4.x, c4.y};
+#pragma unroll
+            for (int k = 0; k < CH; ++k) acc2[k] = tri_f2{0.f, 0.f};
+        }
+        {
+            // first row index of this wave that is still live (r = wave + 8 i >= r0), and its batch of 8 row indices
+            const int i0 = r0 > wave ? (r0 - wave + 7) >> 3 : 0;
+            switch (i0 >> 3) {
+                PK_BATCH(0)
+                PK_BATCH(1)
+                PK_BATCH(2)
+                PK_BATCH(3)
+                PK_BATCH(4)
+                PK_BATCH(5)
+                default: break;
+            }
+        }
+        if (wave == (r0 & (WAVES - 1))) {
+            const int i0r = r0 >> 3, half = i0r & 1;
+            const float capfix = pl == (r0 & 63) ? 2.f : 1.f;     // the halved diagonal entry, whole again
+            switch (i0r >> 1) {
+                PK_CAP(0) PK_CAP(1) PK_CAP(2) PK_CAP(3) PK_CAP(4) PK_CAP(5) PK_CAP(6) PK_CAP(7)
+                PK_CAP(8) PK_CAP(9) PK_CAP(10) PK_CAP(11) PK_CAP(12) PK_CAP(13) PK_CAP(14) PK_CAP(15)
+                PK_CAP(16) PK_CAP(17) PK_CAP(18) PK_CAP(19) PK_CAP(20) PK_CAP(21) PK_CAP(22) PK_CAP(23)
+                default: break;
+            }
+        }
+        {
+            tri_f32x4* pp = (tri_f32x4*)&part[wave][lane][0];
+            pp[0] = tri_f32x4{acc2[0].x + acc2[0].y, acc2[1].x + acc2[1].y, acc2[2].x + acc2[2].y, acc2[3].x + acc2[3].y};
+            pp[1] = tri_f32x4{acc2[4].x + acc2[4].y, acc2[5].x + acc2[5].y, 0.f, 0.f};
+        }
+        PK_STAMP(1);
+        lds_barrier();                                                                     // A
+        PK_STAMP(2);
+        if (wave == 0) {
+            // ---- the scalar part of the step: one wave, wave-level sums only
+            float sc[CH], uc[CH];
+            uc[0] = UC[0].x; uc[1] = UC[0].y; uc[2] = UC[1].x; uc[3] = UC[1].y; uc[4] = UC[2].x; uc[5] = UC[2].y;
+            // the diagonal entry of the captured row (column r0: chunk r0 >> 6, lane pi(r0 & 63)): a uniform read
+            const float cap_r0 = cap[(r0 >> 6) * 64 + pk_pi(r0 & 63)];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) sc[k] = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const tri_f32x4* pp = (const tri_f32x4*)&part[w][lane][0];
+                const tri_f32x4 p0 = pp[0];
+                const tri_f2 p1 = *(const tri_f2*)&pp[1];
+                sc[0] += p0.x; sc[1] += p0.y; sc[2] += p0.z; sc[3] += p0.w; sc[4] += p1.x; sc[5] += p1.y;
+            }
+            float pc[CH], capc[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                // row sums of row c = 64 k + pi(lane): wave c & 7 = lane >> 3, index c >> 3 = 8 k + (lane & 7)
+                const float y = yrows[lane >> 3][8 * k + (lane & 7)];
+                pc[k] = tau * (sc[k] + y);
+                capc[k] = cap[k * 64 + lane];
+            }
+            PK_STAMP(3);
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) dot = fmaf(pc[k], uc[k], dot);
+            const float p_r0 = pick(pc, r0);
+            const float gamma = -0.5f * tau * wave_sum(dot);
+            const float w0 = p_r0 + gamma;                     // u[r0] = 1
+            float wn[CH], cn[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const bool on = pl + 64 * k >= r0;
+                wn[k] = on ? fmaf(gamma, uc[k], pc[k]) : 0.f;
+                cn[k] = on ? capc[k] - fmaf(uc[k], w0, wn[k]) : 0.f;
+            }
+            PK_STAMP(4);
+            // d of the next step = entry r0 of that row = cap - (1 * w0 + w0): the same arithmetic as cn[] at column r0
+            next_reflector(jl + 1, jl + 1 >= n - 1, cn, uc, wn, cap_r0 - fmaf(1.f, w0, w0));
+            PK_STAMP(5);
+        }
+        lds_barrier();                                                                     // B
+        PK_STAMP(6);
+        store_reflector(jl + 1);
+    }
+    lds_barrier();
+    {
+        float* dz = d + (long)z * n;
+        float* ez = e + (long)z * n;
+        float* tz = tau_out + (long)z * n;
+        for (int c = tid; c < n; c += 64 * WAVES) {
+            dz[c] = dloc[c];
+            ez[c] = eloc[c];
+            tz[c] = tloc[c];
+        }
+    }
+    if (rk.rank_out && z < rk.count) {
+        __syncthreads();
+        mp_rank_block(dloc, eloc, n, z, rk, nullptr);
+    }
+}
+#undef PK_CHUNK
+#undef PK_PAIR
+#undef PK_BATCH
+#undef PK_CAP
+
+// ---------------------------------------------------------------------------
 // All eigenvalues of the symmetric tridiagonal (d, e) from Sturm counts (LAPACK sstebz), descending.
 // A Sturm count is a chain of n dependent steps, so plain bisection costs ~45 chains per eigenvalue; here
 // every eigenvalue is owned by one DPP row of 16 lanes that evaluates 16 interior points of its bracket per
@@ -1498,8 +1878,10 @@ constexpr int TRI_TAIL_MAX = 256;      // order of the register-resident trailin
 //   BASD_TRIDIAG_PAD      workgroup-id padding between matrices (scatters the members over XCDs; tests)
 //   BASD_TRIDIAG_LAG      member that sleeps every step (tests the hand-off under uneven progress)
 //   BASD_TRIDIAG_THREADS  threads per member
-//   BASD_TRIDIAG_TAIL     0: whole factorisation in the shared stage (the round-1 path); 2: the four-barrier tail kernel
-//                         (tests compare all three)
+//   BASD_TRIDIAG_TAIL     1 (default): orders 257..384 whole in tridiag_packed_kernel (one CU's registers, upper triangle),
+//                         other orders shared stage + tridiag_tail2_kernel; 3: shared stage + tail2 for every order (the
+//                         round-2 path); 2: the same with the four-barrier tail kernel; 0: whole factorisation in the
+//                         shared stage (the round-1 path).  Tests compare all of them.
 struct TridiagTuning {
     int members = 0, pad = -1, lag = -1, threads = 0, tail = 1;
     TridiagTuning() {
@@ -1573,7 +1955,9 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
     float* pend = (float*)((char*)work + gran_bytes);
     int* err = (int*)((char*)work + gran_bytes + (long)batch * 2 * n * 4);
     const bool tail = g_tuning.tail != 0;
-    const int j_stop = !tail ? n - 1 : (n > TRI_TAIL_MAX ? n - TRI_TAIL_MAX : 0);
+    // orders 257..384: the whole factorisation in one CU's registers (upper triangle): no shared stage at all
+    const bool packed = g_tuning.tail == 1 && n > TRI_TAIL_MAX && n <= PK_NMAX;
+    const int j_stop = !tail ? n - 1 : (packed ? 0 : (n > TRI_TAIL_MAX ? n - TRI_TAIL_MAX : 0));
     if (j_stop > 0) {
         const bool vec = (n & 3) == 0 && (a_batch_stride & 3) == 0 && (((uintptr_t)a) & 15) == 0;
         const int P = tridiag_members(n, batch);
@@ -1608,7 +1992,9 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
     if (tail) {
         MpRankOut in_tail = rk;
         if (!fused_rank) in_tail.rank_out = nullptr;
-        if (g_tuning.tail == 2)      // the four-barrier form (16 waves): kept for the tests that compare the two
+        if (packed)
+            tridiag_packed_kernel<<<batch, 64 * PK_WAVES, 0, stream>>>(a, a_batch_stride, n, d, e, tau, vh, in_tail);
+        else if (g_tuning.tail == 2)      // the four-barrier form (16 waves): kept for the tests that compare the two
             tridiag_tail_kernel<16, 16, 4><<<batch, 1024, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
         else
             tridiag_tail2_kernel<<<batch, 512, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
