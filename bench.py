@@ -85,19 +85,19 @@ def one_step(mod, inp, leaves, logits, bucket):
     for v in leaves.values():
         v.grad = None
     logits.grad = None
-    mod.layer_selector.log_temperatures.grad = None
     loss = mod(logits, inp.targets, leaves, inp.teacher, inp.attn)
     loss.backward()
-    # stand-in student head: per-feature bias gradients (token sums) of every extraction layer fill the front of
-    # the student part of the bucket (the rest keeps its DeiT-S size so that the all-reduce volume is real);
-    # one batched column-sum launch of the library instead of a torch reduction per layer
-    grads = [leaves[l].grad for l in mod.token_layers]
-    rows = grads[0].shape[0] * grads[0].shape[1]
-    sums = ops.column_means(grads)                      # (E, D) means over the B * N token rows
-    bucket.next_slot()                  # ring of two: joins the all-reduce queued on this slot two steps ago
-    bucket.student_view[: sums.numel()].copy_(sums.reshape(-1))
-    bucket.student_view[: sums.numel()].mul_(rows)
-    bucket.pack_loss_grads()            # + the 4 selector temperatures the reference forgets to reduce
+    # stand-in student head: per-feature bias gradients (token means of the first image) of every extraction layer fill
+    # the front of the student part of the bucket (the rest keeps its DeiT-S size so that the all-reduce volume is
+    # real): ONE small column-mean launch of the library straight into the bucket.  (A real student backward would
+    # consume all of the token gradients -- and take tens of milliseconds; round 2's stand-in re-read all 308 MB of them,
+    # which SURVEY 8(d)'s byte count does not contain and which sat in front of the next step's selector chain.)  The
+    # selector temperatures' gradient IS its slice of the bucket (``attach_grads``: the view the trainer uses,
+    # nothing to pack), which the reference forgets to reduce.
+    grads = [leaves[l].grad[:1] for l in mod.token_layers]
+    bucket.wait()                       # the previous step's all-reduce of this buffer (queued async) is joined first
+    ops.column_means(grads, out=bucket.student_view[: len(grads) * grads[0].shape[-1]])
+    bucket.reattach_missing()
     # RCCL over xGMI on the communicator's own stream: it runs underneath the next step's forward (whose teacher /
     # selector side does not depend on the optimizer step); no-op at world size 1
     bucket.all_reduce_mean(async_op=True)
@@ -160,10 +160,10 @@ def launch_check(args, rank: int, world: int) -> None:
     dist.init_process_group("gloo")
     shape = synth.CONFIGS[args.config]
     mod = build(shape, args.config, "cpu")
-    bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), "cpu", slots=2)
+    bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), "cpu")
+    bucket.attach_grads([])
     bucket.student_view.fill_(float(rank + 1))
-    mod.layer_selector.log_temperatures.grad = torch.full((shape.points,), 10.0 * (rank + 1))
-    bucket.pack_loss_grads()
+    mod.layer_selector.log_temperatures.grad.fill_(10.0 * (rank + 1))
     dist.barrier()
     t0 = time.perf_counter()
     bucket.all_reduce_mean(async_op=True)
@@ -224,7 +224,8 @@ def main() -> None:
                             strided=not args.contiguous, attn_on_device=shape.layers_t > 1)
     leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
     logits = inp.logits.detach().requires_grad_(True)
-    bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), device, slots=2)
+    bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), device)
+    bucket.attach_grads([])             # the loss parameters' gradients live in the bucket (views, as in the trainer)
     multi_layer = shape.layers_t > 1
 
     def step():

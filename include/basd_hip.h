@@ -237,9 +237,13 @@ int basd_selector_tail(const float* t_d, const float* t_e, const float* t_tau, c
  *   mode: 0 = one factorisation launch over all 2L + E matrices (student Grams formed on student_stream beside the
  *             teacher's projections);
  *         1 = teacher matrices first; the student side (Grams + factorisation, student_stream != chain_stream) is
- *             held back until the ranks are out;   2 = the same, not held back.
- *   streams: main_stream = the caller's (inputs are ready there); events are opaque handles of basd_event_create:
- *         ev_fork / ev_student / ev_ranks / ev_tail are recorded by the call; ev_slot_free (nullable) is waited for
+ *             held back until the ranks are out;   2 = the same, not held back;
+ *         3 = the same, held back until the teacher's Grams are done (ev_tgram): the student Grams -- the largest MFMA
+ *             launch of the step -- then run beside the teacher's factorisation (two CUs) instead of beside its
+ *             projection and Grams.
+ *   streams: main_stream = the caller's (inputs are ready there; NULL: the caller has recorded ev_fork on it already,
+ *         e.g. before it queued other work the chain need not wait for); events are opaque handles of basd_event_create:
+ *         ev_fork / ev_student / ev_ranks / ev_tail / ev_tgram are recorded by the call; ev_slot_free (nullable) is waited for
  *         before anything is written: the ev_tail of the call that used these buffers last.
  *   Every field is 8 bytes wide.  Device buffers (floats unless noted), n = d_s, M_t = B n_t, nt = ceil(M_t / 128):
  *         z (L, M_t, n); z_sums (L, nt, n); z_ptrs: device table of 2L pointers [z_0..z_{L-1}, z_0..z_{L-1}];
@@ -271,7 +275,7 @@ typedef struct BasdSelectorChain {
     float* zv; float* vecs; float* u_rot; float* sw; float* cos; float* sigma; float* d_out;
     int* k_arr; const int* sw_index; int* jflags;
     hipStream_t main_stream, chain_stream, student_stream, tail_stream;
-    void* ev_fork; void* ev_student; void* ev_ranks; void* ev_tail; void* ev_slot_free;
+    void* ev_fork; void* ev_student; void* ev_ranks; void* ev_tail; void* ev_slot_free; void* ev_tgram;
     /* measurement (all nullable; timed events of basd_event_create_timed, recorded on the stream of the launch they
      * bracket): tm_proj = behind the projections, tm_tgram = behind the teacher Grams, tm_scol0 / tm_scol1 = around the
      * student column means, tm_sgram = behind the student Grams, tm_tri0 = in front of the factorisation (ev_ranks ends

@@ -17,7 +17,8 @@ mod = bench.build(shape, cfg, device)
 inp = synth.make_inputs(shape, 1234, batch=shape.batch, device=device, strided=True, attn_on_device=False)
 leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
 logits = inp.logits.detach().requires_grad_(True)
-bucket = ddp.FlatGradBucket(bench.STUDENT_PARAMS[cfg], list(mod.parameters()), device, slots=2)
+bucket = ddp.FlatGradBucket(bench.STUDENT_PARAMS[cfg], list(mod.parameters()), device)
+bucket.attach_grads([])
 for _ in range(12):
     bench.one_step(mod, inp, leaves, logits, bucket)
 torch.cuda.synchronize()

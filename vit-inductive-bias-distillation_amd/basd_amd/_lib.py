@@ -131,7 +131,7 @@ class SelectorChainArgs(C.Structure):
         + [(n, vp) for n in ("grams", "d", "e", "tau", "vh", "vals", "tri_work", "tri_work_s", "ranks", "host_mirror",
                              "student_status_mirror", "zv", "vecs", "u_rot", "sw", "cos", "sigma", "d_out", "k_arr",
                              "sw_index", "jflags", "main_stream", "chain_stream", "student_stream", "tail_stream",
-                             "ev_fork", "ev_student", "ev_ranks", "ev_tail", "ev_slot_free",
+                             "ev_fork", "ev_student", "ev_ranks", "ev_tail", "ev_slot_free", "ev_tgram",
                              "tm_proj", "tm_tgram", "tm_scol0", "tm_scol1", "tm_sgram", "tm_tri0", "tm_mid", "tm_spec")]
     )
 

@@ -72,7 +72,7 @@ class _Slot:
         b["sw_index"] = torch.tensor(list(range(L)) * E, dtype=i32).to(dev)
         self.mirror = torch.zeros((L + 8,), dtype=i32).pin_memory()
         self.student_mirror = torch.zeros((8,), dtype=i32).pin_memory() if split else None
-        self.ev_fork, self.ev_student, self.ev_ranks, self.ev_tail = (_event() for _ in range(4))
+        self.ev_fork, self.ev_student, self.ev_ranks, self.ev_tail, self.ev_tgram = (_event() for _ in range(5))
         self.used = False                   # ev_tail has been recorded at least once
         self.student_status_pending = False
         self.teacher_ptrs = (C.c_void_p * L)()
@@ -91,6 +91,7 @@ class _Slot:
         a.host_mirror = self.mirror.data_ptr()
         a.student_status_mirror = None if self.student_mirror is None else self.student_mirror.data_ptr()
         a.ev_fork, a.ev_student, a.ev_ranks, a.ev_tail = self.ev_fork, self.ev_student, self.ev_ranks, self.ev_tail
+        a.ev_tgram = self.ev_tgram
 
 
 class SelectorChainPlan:
@@ -136,11 +137,19 @@ class SelectorChainPlan:
         k = min(self.hint + SPEC_MARGIN, self.kmax_cap)
         return k if _lib.query("basd_jacobi_lds_square_fits", k) else 0
 
+    def fork(self, main_stream: int) -> None:
+        """Mark the point of the caller's stream the NEXT ``queue`` may start behind (its inputs are ready there); work the
+        caller queues after this call is not waited for by the chain."""
+        _lib.call("basd_event_record", self.slots[self.turn].ev_fork, main_stream)
+        self._forked = True
+
     def queue(self, students, teachers, proj_t: torch.Tensor, proj_s_t: torch.Tensor, main_stream: int) -> _Slot:
         """Queue the whole selector of this step; returns the slot whose ``ev_ranks`` / ``mirror`` the host reads."""
         slot = self.slots[self.turn]
         self.turn ^= 1
         a = slot.args
+        if getattr(self, "_forked", False):
+            main_stream, self._forked = None, False
         for l, t in enumerate(teachers):
             slot.teacher_ptrs[l] = t.data_ptr()
         a.student_ptrs = ops._ptr_table(students).data_ptr()
@@ -164,6 +173,10 @@ class SelectorChainPlan:
         if marks is not None:
             marks["ranks"] = _event(True)           # behind the factorisation + rank kernel, on the chain stream
             _lib.call("basd_event_record", marks["ranks"], self.chain_stream.cuda_stream)
+            marks["student_end"] = _event(True)
+            _lib.call("basd_event_record", marks["student_end"], self.student_stream.cuda_stream)
+            marks["tail_end"] = _event(True)        # behind whatever of the tail this call queued
+            _lib.call("basd_event_record", marks["tail_end"], self.tail_stream.cuda_stream)
             TIMING.append(marks)
         slot.used = slot.used or slot.kmax > 0
         slot.student_status_pending = self.mode != 0

@@ -50,12 +50,14 @@ class FlatGradBucket:
         autograd then accumulates straight into it and the optimizer reads the reduced values out of it -- no
         per-parameter pack / unpack kernels.  Needs ``slots == 1`` and fp32 parameters on the buffer's device."""
         assert len(self._slots) == 1, "gradient views need one buffer: the optimizer reads the gradients where they are reduced"
-        params = list(student_params) + self.loss_params
-        assert sum(p.numel() for p in student_params) == self.student_numel
+        # an empty list: only the loss parameters are attached (behind the student part, which the caller fills itself)
+        assert not student_params or sum(p.numel() for p in student_params) == self.student_numel
         self.buffer.zero_()
-        off = 0
         self._attached = []
-        for p in params:
+        off = 0
+        if not student_params:
+            off = self.student_numel
+        for p in list(student_params) + self.loss_params:
             n = p.numel()
             assert p.dtype == torch.float32 and p.device == self.buffer.device
             view = self.buffer[off:off + n].view_as(p)

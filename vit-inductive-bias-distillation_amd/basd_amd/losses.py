@@ -958,7 +958,9 @@ class BASDLoss(nn.Module):
         # single-teacher steps: the selector as ONE library call into a persistent workspace (basd_selector_chain);
         # BASD_SELECTOR_CHAIN=0 keeps the kernel-by-kernel layout.  chain_mode: see BasdSelectorChain.mode
         self.use_chain = os.environ.get("BASD_SELECTOR_CHAIN", "1") != "0"
-        self.chain_mode = int(os.environ.get("BASD_CHAIN_MODE", "0"))
+        self.chain_mode = int(os.environ.get("BASD_CHAIN_MODE", "3"))
+        # which of the step's two chains the host queues first: the Procrustes kernels of the caller's stream or the selector
+        self.procrustes_first = os.environ.get("BASD_PROCRUSTES_FIRST", "0") == "1"
         self._chain_plans: dict = {}
 
     def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
@@ -1099,20 +1101,27 @@ class BASDLoss(nn.Module):
         proj_t = sel.proj_t if sel.proj_t.dtype == torch.float32 and sel.proj_t.is_contiguous() \
             else sel.proj_t.float().contiguous()
         ops.gpu_mark("chain_begin")
-        slot = plan.queue(xs, teachers, proj_t, sel._proj_s_transposed(), main.cuda_stream)
-        ops.trace("chains_queued")
+        slot = None
+        if self.procrustes_first:
+            plan.fork(main.cuda_stream)        # the chain starts behind THIS point, not behind the kernels queued next
+        else:
+            slot = plan.queue(xs, teachers, proj_t, sel._proj_s_transposed(), main.cuda_stream)
+            ops.trace("chains_queued")
         ce_loss = _base_loss(self.base_criterion, student_output, targets)
         # softmax over ONE logit: the mixing weights are exactly 1 and d loss / d temperature exactly 0
         mix = ops._device_consts((1.0,) * len(students), torch.float32, main.device).view(-1, 1)
         total, geo_layers = _SingleTeacherTotal.apply(ce_loss, bool(self.teacher_has_cls_token),
                                                       sel.log_temperatures, teachers, attns, *students)
         ops.trace("procrustes_queued")
+        if slot is None:
+            slot = plan.queue(xs, teachers, proj_t, sel._proj_s_transposed(), main.cuda_stream)
+            ops.trace("chains_queued")
 
         def complete():
             nonlocal slot
             ranks, status = plan.read_ranks(slot)
             ops.trace("ranks_read")
-            if status[0]:
+            if status[0]:       # (words 6, 7 may carry clock readings: BASD_TRIDIAG_CLOCKS)
                 # workgroups sharing a matrix lost each other (bounded spin): degrade, do not die -- the selector of
                 # THIS step once more with one workgroup per matrix, and keep that setting
                 _single_member_mode("workgroups sharing a matrix timed out waiting for each other "

@@ -167,17 +167,31 @@ def _gram_layout(xs: list[torch.Tensor]):
     return (dt, sb, sn, sd, rpb), rows, xs[0].shape[-1], vec_ok
 
 
-def column_means(xs: list[torch.Tensor]) -> torch.Tensor:
-    """Column means of same-layout (B,N,D) / (M,D) views in one launch (+ fold) -> (n, D) fp32."""
+_COLMEAN_SCRATCH: dict = {}
+
+
+def column_means(xs: list[torch.Tensor], out: torch.Tensor | None = None) -> torch.Tensor:
+    """Column means of same-layout (B,N,D) / (M,D) views in one launch (+ fold) -> (n, D) fp32.
+    ``out``: a contiguous fp32 buffer of n * D elements to receive them (e.g. a slice of a gradient bucket)."""
     (dt, sb, sn, sd, rpb), rows, cols, vec_ok = _gram_layout(xs)
     n, dev = len(xs), xs[0].device
     table = _ptr_table(xs)
-    means = torch.empty((n, cols), device=dev, dtype=torch.float32)
+    if out is None:
+        means = torch.empty((n, cols), device=dev, dtype=torch.float32)
+    else:
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n * cols and out.device == dev
+        means = out
     parts = _lib.query("basd_colmean_parts", rows)
-    partial = torch.empty((n, parts, cols), device=dev, dtype=torch.float32)
+    # the per-slice partial sums only live between the two launches of this call: one buffer per (shape, stream)
+    key = (n, parts, cols, dev, _stream())
+    partial = _COLMEAN_SCRATCH.get(key)
+    if partial is None:
+        if len(_COLMEAN_SCRATCH) >= 16:
+            _COLMEAN_SCRATCH.clear()
+        partial = _COLMEAN_SCRATCH[key] = torch.empty((n, parts, cols), device=dev, dtype=torch.float32)
     _lib.call("basd_colmean_multi", table.data_ptr(), dt, sb, sn, sd, rpb, rows, cols, n, parts, partial.data_ptr(),
               means.data_ptr(), vec_ok, _stream())
-    return means
+    return means.view(n, cols)
 
 
 def centered_grams(xs: list[torch.Tensor], *, centered: list[bool] | None = None,

@@ -12,6 +12,7 @@
 // largest rank; the caller re-queues the tail (basd_selector_chain_tail) in the rare step where the rank grew past it.
 #include "basd_common.h"
 #include "../../include/basd_hip.h"
+#include <stdlib.h>
 
 namespace basd {
 
@@ -136,7 +137,7 @@ int basd_selector_chain(const BasdSelectorChain* a) {
                    a->tau && a->vh && a->tri_work && a->ranks && a->ev_fork && a->ev_student && a->ev_ranks && a->ev_tail);
     const int E = (int)a->E, L = (int)a->L, B = (int)a->B, n_s = (int)a->n_s, n_t = (int)a->n_t;
     const int n = (int)a->d_s, d_t = (int)a->d_t, mode = (int)a->mode;
-    BASD_CHECK_ARG(E > 0 && L > 0 && B > 0 && n > 1 && d_t > 0 && mode >= 0 && mode <= 2);
+    BASD_CHECK_ARG(E > 0 && L > 0 && B > 0 && n > 1 && d_t > 0 && mode >= 0 && mode <= 3);
     const long M_t = (long)B * n_t, M_s = (long)B * n_s;
     // the uncentred Gram is formed on the feature side (layer_selector.py:12-13); the token-side form (:14-15, fewer
     // rows than features) has a different order: not covered here, the caller takes the per-kernel entry points
@@ -147,7 +148,8 @@ int basd_selector_chain(const BasdSelectorChain* a) {
 
     // ---- order against the caller: inputs are ready on main_stream; this slot's buffers are free once the tail that
     // read them last has finished
-    BASD_HIP(hipEventRecord((hipEvent_t)a->ev_fork, a->main_stream));
+    // (main_stream NULL: the caller has recorded ev_fork itself, at the point of ITS stream the chain may start behind)
+    if (a->main_stream) BASD_HIP(hipEventRecord((hipEvent_t)a->ev_fork, a->main_stream));
     BASD_HIP(hipStreamWaitEvent(cs, (hipEvent_t)a->ev_fork, 0));
     if (ss != cs) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_fork, 0));
     if (a->ev_slot_free) {
@@ -165,6 +167,10 @@ int basd_selector_chain(const BasdSelectorChain* a) {
     BASD_TRY(basd_syrk_multi(a->z_ptrs, BASD_DTYPE_F32, 0, n, 1, 1 << 30, (int)M_t, n, 2 * L, nullptr, a->t_scales,
                              (int)a->t_splits, a->t_slabs, a->grams, nn, 1, a->z_sums, tiles, L, cs));
     BASD_MARK(a->tm_tgram, cs);
+    if (mode == 3) {
+        BASD_CHECK_ARG(a->ev_tgram != nullptr);
+        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_tgram, cs));
+    }
 
     auto student_grams = [&](hipStream_t st) -> int {
         // centred Grams of the E student layers (:88-91; proj_s folded into the principal angles)
@@ -199,6 +205,7 @@ int basd_selector_chain(const BasdSelectorChain* a) {
         BASD_HIP(hipEventRecord((hipEvent_t)a->ev_ranks, cs));
         BASD_CHECK_ARG(a->tri_work_s != nullptr && ss != cs);
         if (mode == 1) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_ranks, 0));
+        if (mode == 3) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_tgram, 0));
         BASD_TRY(student_grams(ss));
         BASD_TRY(basd_tridiag(a->grams + 2L * L * nn, nn, n, E, a->d + 2L * L * n, a->e + 2L * L * n,
                               a->tau + 2L * L * n, a->vh + 2L * L * nn, a->tri_work_s, ss));

@@ -965,6 +965,11 @@ __device__ __forceinline__ void pk_fma_bc(tri_f2& acc, tri_f2 a, tri_f2 b) {    
     if constexpr (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
     else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b));
 }
+template <int H>
+__device__ __forceinline__ void pk_fnma_bc(tri_f2& acc, tri_f2 a, tri_f2 b) {     // acc -= a * b[H] (neg modifiers: free)
+    if constexpr (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ void pk_fma(tri_f2& acc, tri_f2 a, tri_f2 b) {          // acc += a * b
     asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
@@ -1027,8 +1032,8 @@ __device__ __forceinline__ int pk_pi(int l) { return 8 * (l & 7) + (l >> 3); }
 #define PK_CHUNK(P, K, VAB, WAB, U2)                                               \
     if constexpr ((K) >= ((P) >> 2) && (K) < PK_CH) {                              \
         tri_f2 a_ = A2[pk_idx(P, K)];                                              \
-        pk_fma_bc<(K) & 1>(a_, VAB, NW[(K) >> 1]);                                 \
-        pk_fma_bc<(K) & 1>(a_, WAB, NV[(K) >> 1]);                                 \
+        pk_fnma_bc<(K) & 1>(a_, VAB, NW[(K) >> 1]);                                \
+        pk_fnma_bc<(K) & 1>(a_, WAB, NV[(K) >> 1]);                                \
         A2[pk_idx(P, K)] = a_;                                                     \
         pk_fma(acc2[K], a_, U2);                                                   \
         pk_fma_bc<(K) & 1>(t2[(P) & 3], a_, UC[(K) >> 1]);                         \
@@ -1080,12 +1085,17 @@ __device__ __forceinline__ int pk_pi(int l) { return 8 * (l & 7) + (l >> 3); }
 __global__ void __launch_bounds__(64 * PK_WAVES) tridiag_packed_kernel(float* __restrict__ A, long a_batch_stride, int n,
                                                                        float* __restrict__ d, float* __restrict__ e,
                                                                        float* __restrict__ tau_out,
-                                                                       float* __restrict__ Vh, MpRankOut rk) {
+                                                                       float* __restrict__ Vh, MpRankOut rk,
+                                                                       int clocks) {
     constexpr int WAVES = PK_WAVES, CH = PK_CH;
     __builtin_amdgcn_s_setprio(3);
+    // diagnostics (BASD_TRIDIAG_CLOCKS=1): how long this workgroup ran, on the constant 100 MHz clock and on the shader
+    // clock -- status words 6 and 7, which travel to the host with the ranks, tell a run that WAITED for a free CU from
+    // one that was slow
+    const long long wall0 = wall_clock64(), clk0 = clock64();
     // row operands of the pass: [wave][batch kb][v x 8 | w x 8 | u x 8], slot = i & 7 of row w + 8 i, i = 8 kb + slot
     __shared__ __attribute__((aligned(16))) float optab[WAVES][CH][24];
-    // column operands per lane (c = 64 k + pi(l)): u[6], -v[6], -w[6], 2 pad: five b128
+    // column operands per lane (c = 64 k + pi(l)): u[6], v[6], w[6], 2 pad: five b128
     __shared__ __attribute__((aligned(16))) float colf[64][20];
     __shared__ __attribute__((aligned(16))) float part[WAVES][64][8];        // per-wave column partials (6 of 8 used)
     __shared__ __attribute__((aligned(16))) float yrows[WAVES][PK_RPW];      // cross-lane row sums of row w + 8 i
@@ -1161,10 +1171,10 @@ __global__ void __launch_bounds__(64 * PK_WAVES) tridiag_packed_kernel(float* __
         }
         tri_f32x4* cf = (tri_f32x4*)&colf[lane][0];
         cf[0] = tri_f32x4{un[0], un[1], un[2], un[3]};
-        cf[1] = tri_f32x4{un[4], un[5], -uc[0], -uc[1]};
-        cf[2] = tri_f32x4{-uc[2], -uc[3], -uc[4], -uc[5]};
-        cf[3] = tri_f32x4{-wn[0], -wn[1], -wn[2], -wn[3]};
-        cf[4] = tri_f32x4{-wn[4], -wn[5], 0.f, 0.f};
+        cf[1] = tri_f32x4{un[4], un[5], uc[0], uc[1]};
+        cf[2] = tri_f32x4{uc[2], uc[3], uc[4], uc[5]};
+        cf[3] = tri_f32x4{wn[0], wn[1], wn[2], wn[3]};
+        cf[4] = tri_f32x4{wn[4], wn[5], 0.f, 0.f};
         if (lane == 0) {
             dloc[jl] = dnew;
             eloc[jl] = beta;
@@ -1197,7 +1207,7 @@ __global__ void __launch_bounds__(64 * PK_WAVES) tridiag_packed_kernel(float* __
         tri_f2 NV[3], NW[3], UC[3], acc2[CH];
         {
             const tri_f32x4* cf = (const tri_f32x4*)&colf[lane][0];
-            const tri_f32x4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4];   // u0-3 | u4,u5,-v0,-v1 | -v2-5 | -w0-3 | -w4,-w5
+            const tri_f32x4 c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3], c4 = cf[4];   // u0-3 | u4,u5,v0,v1 | v2-5 | w0-3 | w4,w5
             UC[0] = tri_f2{c0.x, c0.y}; UC[1] = tri_f2{c0.z, c0.w}; UC[2] = tri_f2{c1.x, c1.y};
             NV[0] = tri_f2{c1.z, c1.w}; NV[1] = tri_f2{c2.x, c2.y}; NV[2] = tri_f2{c2.z, c2.w};
             NW[0] = tri_f2{c3.x, c3.y}; NW[1] = tri_f2{c3.z, c3.w}; NW[2] = tri_f2{c4.x, c4.y};
@@ -1236,41 +1246,56 @@ __global__ void __launch_bounds__(64 * PK_WAVES) tridiag_packed_kernel(float* __
         lds_barrier();                                                                     // A
         PK_STAMP(2);
         if (wave == 0) {
-            // ---- the scalar part of the step: one wave, wave-level sums only
-            float sc[CH], uc[CH];
+            // ---- the scalar part of the step: one wave, wave-level sums only; column pairs (k, k + 1) as packed math
+            float uc[CH];
             uc[0] = UC[0].x; uc[1] = UC[0].y; uc[2] = UC[1].x; uc[3] = UC[1].y; uc[4] = UC[2].x; uc[5] = UC[2].y;
             // the diagonal entry of the captured row (column r0: chunk r0 >> 6, lane pi(r0 & 63)): a uniform read
             const float cap_r0 = cap[(r0 >> 6) * 64 + pk_pi(r0 & 63)];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) sc[k] = 0.f;
+            tri_f2 sc2[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) {
                 const tri_f32x4* pp = (const tri_f32x4*)&part[w][lane][0];
                 const tri_f32x4 p0 = pp[0];
                 const tri_f2 p1 = *(const tri_f2*)&pp[1];
-                sc[0] += p0.x; sc[1] += p0.y; sc[2] += p0.z; sc[3] += p0.w; sc[4] += p1.x; sc[5] += p1.y;
+                sc2[0] = pk_add(sc2[0], tri_f2{p0.x, p0.y});
+                sc2[1] = pk_add(sc2[1], tri_f2{p0.z, p0.w});
+                sc2[2] = pk_add(sc2[2], p1);
             }
-            float pc[CH], capc[CH];
+            tri_f2 pc2[3], capc2[3];
+            const tri_f2 tau2 = {tau, tau};
 #pragma unroll
-            for (int k = 0; k < CH; ++k) {
+            for (int q = 0; q < 3; ++q) {
                 // row sums of row c = 64 k + pi(lane): wave c & 7 = lane >> 3, index c >> 3 = 8 k + (lane & 7)
-                const float y = yrows[lane >> 3][8 * k + (lane & 7)];
-                pc[k] = tau * (sc[k] + y);
-                capc[k] = cap[k * 64 + lane];
+                const tri_f2 y2 = {yrows[lane >> 3][16 * q + (lane & 7)], yrows[lane >> 3][16 * q + 8 + (lane & 7)]};
+                pc2[q] = pk_mul(tau2, pk_add(sc2[q], y2));
+                capc2[q] = tri_f2{cap[128 * q + lane], cap[128 * q + 64 + lane]};
             }
             PK_STAMP(3);
-            float dot = 0.f;
+            tri_f2 dot2 = {0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < CH; ++k) dot = fmaf(pc[k], uc[k], dot);
+            for (int q = 0; q < 3; ++q) pk_fma(dot2, pc2[q], UC[q]);
+            float pc[CH];
+            pc[0] = pc2[0].x; pc[1] = pc2[0].y; pc[2] = pc2[1].x; pc[3] = pc2[1].y; pc[4] = pc2[2].x; pc[5] = pc2[2].y;
             const float p_r0 = pick(pc, r0);
-            const float gamma = -0.5f * tau * wave_sum(dot);
+            const float gamma = -0.5f * tau * wave_sum(dot2.x + dot2.y);
             const float w0 = p_r0 + gamma;                     // u[r0] = 1
+            // No masks for the columns c < r0 (tridiag_tail2_kernel needs them: it stores full rows): with the upper
+            // triangle no live row holds such a column -- as COLUMN operands (u, v, w)_c only ever meet padding lanes
+            // (masked), as ROW operands they belong to finished rows, whose u is 0 (next_reflector) and whose registers
+            // nothing reads any more; everything stays finite (sums of finite products).
             float wn[CH], cn[CH];
+            {
+                const tri_f2 g2 = {gamma, gamma}, w02 = {w0, w0};
 #pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const bool on = pl + 64 * k >= r0;
-                wn[k] = on ? fmaf(gamma, uc[k], pc[k]) : 0.f;
-                cn[k] = on ? capc[k] - fmaf(uc[k], w0, wn[k]) : 0.f;
+                for (int q = 0; q < 3; ++q) {
+                    tri_f2 wn2 = pc2[q];
+                    pk_fma(wn2, g2, UC[q]);                    // w = p + gamma u
+                    tri_f2 t2_ = wn2;
+                    pk_fma(t2_, UC[q], w02);                   // u w0 + w
+                    const tri_f2 cn2 = pk_add(capc2[q], tri_f2{-t2_.x, -t2_.y});
+                    wn[2 * q] = wn2.x; wn[2 * q + 1] = wn2.y;
+                    cn[2 * q] = cn2.x; cn[2 * q + 1] = cn2.y;
+                }
             }
             PK_STAMP(4);
             // d of the next step = entry r0 of that row = cap - (1 * w0 + w0): the same arithmetic as cn[] at column r0
@@ -1291,6 +1316,11 @@ __global__ void __launch_bounds__(64 * PK_WAVES) tridiag_packed_kernel(float* __
             ez[c] = eloc[c];
             tz[c] = tloc[c];
         }
+    }
+    if (clocks && z == 0 && tid == 0 && rk.status) {
+        int* st = const_cast<int*>(rk.status);
+        st[6] = (int)(wall_clock64() - wall0);          // x 10 ns
+        st[7] = (int)((clock64() - clk0) >> 4);         // shader cycles / 16
     }
     if (rk.rank_out && z < rk.count) {
         __syncthreads();
@@ -1646,22 +1676,42 @@ __global__ void __launch_bounds__(256) backtransform_kernel(const float* __restr
         const int r = lane + 64 * i;
         x[i] = r < n ? zz[r] : 0.f;
     }
-    for (int jj = 0; jj <= n - 2; ++jj) {
+    // A chain of n - 1 dependent reflector applications, each needing one row of Vh from L2 (~1 us away): the rows are
+    // fetched PF steps ahead into a ring of registers (their addresses do not depend on the chain), so a step costs its
+    // dot product and wave sum, not a memory round trip (0.28 ms -> the arithmetic at n = 384).
+    constexpr int PF = EPL <= 6 ? 8 : 4;
+    float ring[PF][EPL];
+    float tring[PF];
+    auto fetch = [&](int jj, float (&dst)[EPL], float& tdst) {
         const int j = FWD ? jj : n - 2 - jj;
-        const float tj = tz[j];
-        if (tj == 0.f) continue;
-        const float* vj = Vz + (long)j * n;
-        float vr[EPL];
-        float s = 0.f;
+        const bool ok = jj <= n - 2;
+        const float* vj = Vz + (long)(ok ? j : 0) * n;
+        tdst = ok ? tz[j] : 0.f;
 #pragma unroll
         for (int i = 0; i < EPL; ++i) {
             const int r = lane + 64 * i;
-            vr[i] = r < n ? vj[r] : 0.f;
-            s = fmaf(vr[i], x[i], s);
+            dst[i] = (ok && r < n) ? vj[r] : 0.f;
         }
-        s = wave_sum(s) * tj;
+    };
 #pragma unroll
-        for (int i = 0; i < EPL; ++i) x[i] = fmaf(-s, vr[i], x[i]);
+    for (int p = 0; p < PF; ++p) fetch(p, ring[p], tring[p]);
+    for (int j0 = 0; j0 <= n - 2; j0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            float vr[EPL];
+            const float tj = tring[p];
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) vr[i] = ring[p][i];
+            fetch(j0 + p + PF, ring[p], tring[p]);          // the slot's next tenant is requested before this one is used
+            if (tj != 0.f) {                                 // (wave-uniform; rows past the end come back with tau = 0)
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) s = fmaf(vr[i], x[i], s);
+                s = wave_sum(s) * tj;
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) x[i] = fmaf(-s, vr[i], x[i]);
+            }
+        }
     }
     float* o = out + ((long)z * out_stride_k + t) * n;
 #pragma unroll
@@ -1893,6 +1943,7 @@ struct TridiagTuning {
     }
 };
 static TridiagTuning g_tuning;
+static const int g_pk_clocks = getenv("BASD_TRIDIAG_CLOCKS") ? atoi(getenv("BASD_TRIDIAG_CLOCKS")) : 0;   // diagnostics
 
 // Workgroups of one shared-stage launch that may spin on each other: all of them must be resident together, beside
 // whatever the other streams keep on the chip.  Half of what the device can hold of this kernel (occupancy query for
@@ -1993,7 +2044,7 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
         MpRankOut in_tail = rk;
         if (!fused_rank) in_tail.rank_out = nullptr;
         if (packed)
-            tridiag_packed_kernel<<<batch, 64 * PK_WAVES, 0, stream>>>(a, a_batch_stride, n, d, e, tau, vh, in_tail);
+            tridiag_packed_kernel<<<batch, 64 * PK_WAVES, 0, stream>>>(a, a_batch_stride, n, d, e, tau, vh, in_tail, g_pk_clocks);
         else if (g_tuning.tail == 2)      // the four-barrier form (16 waves): kept for the tests that compare the two
             tridiag_tail_kernel<16, 16, 4><<<batch, 1024, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
         else
