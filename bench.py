@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "vit-inductive-bias-distillation_amd"))
 import torch
 import torch.distributed as dist
 
-from basd_amd import _lib, ddp, ops, synth
+from basd_amd import _lib, chain, ddp, ops, synth
 from basd_amd.losses import BASDLoss
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -57,11 +57,11 @@ def algorithmic_bytes(shape: synth.LossShape, batch: int, elem: int = 4) -> dict
     return {"fwd": fwd, "bwd": fwd + grad, "step": 2 * fwd + grad, "student": student, "student_grad": grad}
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
 def measured_traffic(cfg: str) -> dict:
-    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/r02_traffic.json, written by
+    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/r03_traffic.json, written by
     tools/pmc_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE); {} when not
     collected.  These are numbers of an EARLIER profiled run of this command, copied into the line: `traffic_source`
     says so."""
@@ -195,6 +195,13 @@ def main() -> None:
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point time table to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
+    ap.add_argument("--cpu-repeats", type=int, default=3)
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="time only the CPU oracle (e.g. --cpu-sample-batch 256 --cpu-repeats 1 for the full headline batch) "
+                         "and print its record; no GPU call")
+    ap.add_argument("--teacher-rank", type=int, default=0,
+                    help="signal rank of the synthetic teacher features (default: the config's 48); e.g. 160 ~ what a "
+                         "random-init ResNet-50 feeds the selector: a secondary workload, named in config.workload")
     ap.add_argument("--launch-check", action="store_true",
                     help="CPU rehearsal of the N > 1 launch: gloo group + one all-reduce of the gradient bucket, no GPU call")
     args = ap.parse_args()
@@ -209,12 +216,21 @@ def main() -> None:
     if args.launch_check:
         launch_check(args, rank, world)
         return
+    if args.cpu_baseline_only:
+        shape0 = synth.CONFIGS[args.config]
+        print(json.dumps({"cpu_baseline": cpu_baseline(args.config, shape0, min(args.cpu_sample_batch, shape0.batch),
+                                                       repeats=args.cpu_repeats)}))
+        return
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
     shape = synth.CONFIGS[args.config]
+    if args.teacher_rank > 0:
+        import dataclasses
+        shape = dataclasses.replace(shape, r_t=args.teacher_rank,
+                                    name=f"{shape.name} (synthetic teacher signal rank {args.teacher_rank})")
     batch = args.batch or shape.batch
     mod = build(shape, args.config, device)
     # per-rank minibatch (weak scaling): seed 1234 + rank, generated once, resident in HBM
@@ -249,6 +265,9 @@ def main() -> None:
     timed = {"basd_tridiag", "basd_tridiag_ranked", "basd_syrk_multi", "basd_colmean_multi", "basd_jacobi_onesided"}
     _lib.timing = {}
     _lib.timed_names = None if args.breakdown else timed
+    # single-teacher steps queue the selector inside ONE library call (basd_selector_chain): there the same launches are
+    # bracketed by timed events the call records itself, on the stream each launch is queued on
+    chain.TIMING = []
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -262,12 +281,31 @@ def main() -> None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timing, _lib.timing = _lib.timing, None
+    marks, chain.TIMING = chain.TIMING, None
+    own_ms = 1e3 * elapsed / args.steps
+    ms_min = ms_max = own_ms
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, -elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, ms_min, ms_max = float(t[0].item()), 1e3 * float(-t[1].item()) / args.steps, 1e3 * float(t[0].item()) / args.steps
 
     per_call = {k: [a.elapsed_time(b) for a, b in v] for k, v in timing.items()}      # ms
+
+    def span(a: str, b: str) -> list:
+        """per-step duration (ms) between two marks of the selector chain"""
+        out = []
+        for m in marks:
+            try:
+                out.append(1e-3 * chain.elapsed_us(m[a], m[b]))
+            except (KeyError, RuntimeError):
+                pass
+        return out
+    if marks:
+        # same names as the entry points the kernel-by-kernel layout times; the factorisation the host waits for is the
+        # teacher side's (its span contains the wait for a free CU and the rank kernel: what the step pays)
+        per_call["basd_tridiag_ranked"] = span("tm_tri0", "ranks")
+        per_call["basd_syrk_multi"] = span("tm_scol1", "tm_sgram")
+        per_call["basd_colmean_multi"] = span("tm_scol0", "tm_scol1")      # (not the stand-in head's small launch)
     if args.breakdown and rank == 0:
         tot = sum(sum(v) for v in per_call.values())
         print(f"{'entry point':32s} {'calls/step':>10s} {'ms/step':>9s} {'share':>6s}", file=sys.stderr)
@@ -286,42 +324,67 @@ def main() -> None:
                           "command (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), not collected in this run"
                           if traffic else None)
 
-        def longest(names):
-            """mean duration (ms) of the LONGER of the calls of an entry point per step (student-side call), and the count"""
+        def mean_ms(names):
+            """mean duration (ms) of the calls of these entry points, and calls per step"""
             calls = [c for n in names for c in per_call.get(n, [])]
-            if not calls:
-                return 0.0, 0
-            per_step = max(1, round(len(calls) / args.steps))
-            top = sorted(calls)[-args.steps:] if per_step > 1 else calls
-            return sum(top) / len(top), per_step
+            return (sum(calls) / len(calls), len(calls) / args.steps) if calls else (0.0, 0)
 
         # --- dominant kernel by GPU time: the tridiagonalisation of the selector's Gram matrices
+        chain_step = bool(marks)
         if ops.EIG_SOLVER == "tridiag":
-            eig_ms, eig_calls = longest(["basd_tridiag", "basd_tridiag_ranked"])
-            n_mats = E if L == 1 else max(E, 2 * L)
-            kernel_name = ("tridiag_kernel + tridiag_tail2_kernel (Householder tridiagonalisation of the student Gram "
-                           "matrices; the teacher-side call of the same entry point runs beside it)")
-            note = ("latency-bound, neither an HBM stream nor MFMA work: n - 1 dependent Householder steps (first stage: "
-                    "matrix shared by up to 16 workgroups, one L2 round trip + granule hand-off per step; last 256 steps: "
-                    "matrix in one CU's registers, two workgroup barriers and one wave's scalar chain per step).  `bound` is kept to the contract's "
-                    "vocabulary; the HBM fraction says how far from a stream this kernel is by construction.  The "
-                    "roofline-bound kernels of the path are under roofline_mfma / roofline_hbm_stream.")
+            if chain_step:
+                eig_ms, eig_calls = mean_ms(["basd_tridiag_ranked"])
+                n_mats = 2 * L if mod.chain_mode else 2 * L + E
+            else:
+                # kernel-by-kernel layout: every launch of the two entry points, all their matrices
+                eig_ms, eig_calls = mean_ms(["basd_tridiag", "basd_tridiag_ranked"])
+                n_mats = (2 * L + E) / max(eig_calls, 1)
+            packed = 256 < d_s <= 384
+            kernel_name = ("tridiag_packed_kernel (Householder tridiagonalisation, whole factorisation of one matrix in one "
+                           "CU's registers: upper triangle as packed row pairs; teacher-side launch, the one the host waits "
+                           "for)" if packed else
+                           "tridiag_kernel + tridiag_tail2_kernel (Householder tridiagonalisation of the selector's Gram "
+                           "matrices: shared stage + register-resident tail stage)")
+            note = ("latency-bound, neither an HBM stream nor MFMA work: n - 1 dependent Householder steps, each one pass over "
+                    "the register-resident upper triangle + one wave's scalar chain + two workgroup barriers"
+                    if packed else
+                    "latency-bound, neither an HBM stream nor MFMA work: n - 1 dependent Householder steps (first stage: "
+                    "matrix shared by several workgroups through L2; last 256 steps: matrix in one CU's registers)") + \
+                   (".  `bound` is kept to the contract's vocabulary; the HBM fraction says how far from a stream this "
+                    "kernel is by construction.  The roofline-bound kernels of the path are under roofline_mfma / "
+                    "roofline_hbm_stream; the duration is the launch's span on its stream, inside the step")
         else:
-            eig_ms, eig_calls = longest(["basd_jacobi_onesided"])
+            eig_ms, eig_calls = mean_ms(["basd_jacobi_onesided"])
             n_mats = 2 * L + E
             kernel_name = "jacobi_block_round_kernel (block one-sided Jacobi, symmetric eigen-solves of the selector)"
             note = "latency-bound chain of dependent pair-steps, not an HBM stream (DESIGN.md section 5)"
-        launch_bytes = n_mats * 2 * d_s * d_s * 4          # every matrix read once, its reflectors written once
+        launch_bytes = int(n_mats * 2 * d_s * d_s * 4)      # every matrix read once, its reflectors written once
         achieved = launch_bytes / (eig_ms * 1e-3) / 1e9 if eig_ms > 0 else 0.0
-        # --- the MFMA-bound kernel: symmetric Gram of the E student token matrices (lower 128x128 tile pairs only)
-        tiles = (d_s + 127) // 128
-        syrk_ms, _ = longest(["basd_syrk_multi"])
-        syrk_flops = E * (tiles * (tiles + 1) // 2) * 128 * 128 * 2.0 * batch * shape.n_s
+        # --- the MFMA-bound kernel: symmetric Gram launches (lower 128x128 tile pairs only).  The flops are those of the
+        # launches that are TIMED: the student launch (E matrices of order d_s over B n_s rows) in chain steps; in the
+        # kernel-by-kernel layout every syrk launch of the step -- student, and the teacher side's (2L Grams of the
+        # projected tokens, or L Grams in the teacher's own space where the teacher is about as wide as the student)
+        def pairs(n):
+            t = (n + 127) // 128
+            return t * (t + 1) // 2
+        student_flops = E * pairs(d_s) * 128 * 128 * 2.0 * batch * shape.n_s
+        syrk_ms, syrk_calls = mean_ms(["basd_syrk_multi"])
+        if chain_step:
+            syrk_flops = student_flops
+        else:
+            m_t = batch * shape.n_t
+            own_space = m_t >= d_s and shape.d_t <= 1.5 * d_s and mod.layer_selector.teacher_space_gram
+            teacher_flops = (L * pairs(shape.d_t) if own_space else 2 * L * pairs(d_s)) * 128 * 128 * 2.0 * m_t \
+                if m_t >= d_s else 0.0
+            syrk_flops = (student_flops + teacher_flops) / max(syrk_calls, 1)      # per launch, like syrk_ms
         syrk_tf = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         # --- the HBM stream: column sums of the E student token tensors (every element read once, nothing written)
-        # (two launches of the same size per step: the student chain's over the token views, the stand-in head's over
-        # the gradient buffer; the contract asks for the kernel's AVERAGE launch duration: all of them)
-        col_calls = per_call.get("basd_colmean_multi", [])
+        col_calls = [c for c in per_call.get("basd_colmean_multi", []) if c > 0]
+        if not chain_step and col_calls:
+            # the kernel-by-kernel layout times every launch of the entry point, in call order: the student layers' is
+            # the first of a step (then the teacher layers' where their Gram is formed in their own space, then the
+            # stand-in head's small one)
+            col_calls = col_calls[0::max(1, round(len(col_calls) / args.steps))]
         col_ms = sum(col_calls) / len(col_calls) if col_calls else 0.0
         col_bytes = ab["student"]
         col_gbs = col_bytes / (col_ms * 1e-3) / 1e9 if col_ms > 0 else 0.0
@@ -334,6 +397,9 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
+            "ms_per_step_min_max_over_ranks": [ms_min, ms_max],
+            "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": dist.get_backend() if world > 1 else None,
             "steps_per_s": 1e3 / ms_step,
             "higher_is_better": True,
             "scaling": "weak",
@@ -352,6 +418,7 @@ def main() -> None:
                 "grad_allreduce": "RCCL all-reduce (mean) per step on the communicator's stream" if world > 1
                 else "none at world size 1 (bucket packed, nothing to exchange)",
                 "rank_readback": "sync" if mod.sync_ranks else "deferred",
+                "selector": (f"basd_selector_chain mode {mod.chain_mode}" if marks else "kernel by kernel"),
                 "parallelism": f"dp{world}",
             },
             "path_hbm": {
@@ -364,16 +431,17 @@ def main() -> None:
                 "bound": "hbm", "regime": "latency", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get("tridiag"),
                 "traffic_source": traffic_source if traffic.get("tridiag") else None,
-                "launch_ms": eig_ms, "launches_per_step": eig_calls,
+                "launch_ms": eig_ms, "launches_per_step": eig_calls, "matrices_per_launch": n_mats,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "note": note,
             },
             "roofline_mfma": {
-                "kernel": "syrk_tn_kernel (+ syrk_reduce_kernel): centred Gram matrices of the E student layers",
+                "kernel": "syrk_tn_kernel (+ syrk_reduce_kernel): centred Gram matrices of the E student layers" if marks else
+                          "syrk_tn_kernel (+ syrk_reduce_kernel): the step's symmetric Gram launches (student layers; teacher layers)",
                 "bound": "mfma", "achieved": syrk_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": syrk_tf / MFMA_F32_PEAK_TF, "traffic": traffic.get("syrk_tn_kernel"),
                 "traffic_source": traffic_source if traffic.get("syrk_tn_kernel") else None,
-                "launch_ms": syrk_ms, "executed_flops_per_launch": syrk_flops,
+                "launch_ms": syrk_ms, "launches_per_step": syrk_calls, "executed_flops_per_launch": syrk_flops,
                 "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32); flops counted are the lower-triangular 128x128 tile "
                         "pairs actually executed; timed inside the step, i.e. while the other streams' kernels "
                         "share the chip",
@@ -386,14 +454,14 @@ def main() -> None:
                 "launch_ms": col_ms, "launch_ms_min_max": [min(col_calls), max(col_calls)] if col_calls else None,
                 "launches_per_step": len(col_calls) / args.steps,
                 "algorithmic_bytes_per_launch": col_bytes,
-                "note": "every element of E (B, N, D) fp32 token tensors read once, nothing written back; mean over "
-                        "all launches inside the step (the student chain's over the strided CLS-sliced views runs "
-                        "beside the next step's teacher chain, the stand-in head's over the gradient buffer beside "
-                        "the backward)",
+                "note": "every element of E (B, N, D) token tensors read once, nothing written back; the selector's launch "
+                        "over the strided CLS-sliced views, inside the step (beside the teacher side's factorisation and "
+                        "the Procrustes kernels of the caller's stream)",
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.config, shape, min(args.cpu_sample_batch, batch))
+            line["cpu_baseline"] = cpu_baseline(args.config, shape, min(args.cpu_sample_batch, batch),
+                                                repeats=args.cpu_repeats)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -211,6 +211,13 @@ int basd_grassmann_distance(const float* colnorm, int stride, const int* k_arr, 
 
 int basd_sqrt_clamp(const float* in, float* out, long count, hipStream_t stream);
 
+/* Both Grams of the projected teacher tokens z = tokens proj_t^T (layer_selector.py:72 -> :13 and :35) from the centred
+ * Gram of the tokens in THEIR OWN space, for teachers about as wide as the student (D_t <~ 1.5 D_s: ViT teachers) -- z is
+ * never formed: c (batch, n, n) = proj_t G_c proj_t^T (two basd_gemm_nt), zbar (batch, n) = proj_t tbar;
+ * out_c = sym(c) (the centred Gram of z), out_u = (sym(c) + M zbar zbar^T) / M (its uncentred Gram / M, M = m_rows). */
+int basd_gram_finish(const float* c, const float* zbar, int n, int batch, long m_rows, float* out_u, float* out_c,
+                     hipStream_t stream);
+
 /* Everything of the selector that follows the rank read-back, queued by one call (layer_selector.py:36-37, :92,
  * :95-105): leading kmax eigenvectors of the E student / L centred teacher Grams from their basd_tridiag
  * factorisations (t_* / s_*: d, e, tau, vh, vals), S[:k], the teacher bases rotated by proj_s^T, the E x L cosine

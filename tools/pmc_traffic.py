@@ -5,10 +5,11 @@ both derived counters in kilobytes.  Kernels are keyed by short name; where an e
 step (teacher / student side) the LARGER grid's launches are kept."""
 import csv, json, sys, collections
 
-KEYS = {"tridiag_kernel": "tridiag_kernel", "tridiag_tail_kernel": "tridiag_tail_kernel", "syrk_tn_kernel": "syrk_tn_kernel",
+KEYS = {"tridiag_packed_kernel": "tridiag_packed_kernel", "tridiag_kernel": "tridiag_kernel",
+        "tridiag_tail2_kernel": "tridiag_tail_kernel", "syrk_tn_kernel": "syrk_tn_kernel",
         "colsum_partial_vec_kernel": "colsum_partial_vec_kernel", "gemm_nt_kernel<float, false>": "gemm_nt_kernel",
-        "jacobi_lds_kernel<28": "jacobi_lds_kernel", "student_project_v4_kernel": "student_project_v4_kernel",
-        "student_grad_kernel": "student_grad_kernel"}
+        "jacobi_lds_kernel<16, 16, 4>": "jacobi_lds_kernel", "student_project_v4_kernel": "student_project_v4_kernel",
+        "student_grad_fused_kernel": "student_grad_fused_kernel"}
 
 
 def per_kernel(path, counter):
@@ -33,7 +34,8 @@ fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 cfg, out = sys.argv[3], sys.argv[4]
 res = {k: int(2 * fetch[k] * 1024 + write.get(k, 0.0) * 1024) for k in fetch}    # bytes per launch (mean over launches)
-res["tridiag"] = res.get("tridiag_kernel", 0) + res.get("tridiag_tail_kernel", 0)  # the two kernels of one factorisation
+# one factorisation: the packed kernel where it applies (orders 257..384), else the two kernels of the two-stage path
+res["tridiag"] = res.get("tridiag_packed_kernel") or (res.get("tridiag_kernel", 0) + res.get("tridiag_tail_kernel", 0))
 try:
     allc = json.load(open(out))
 except (OSError, ValueError):

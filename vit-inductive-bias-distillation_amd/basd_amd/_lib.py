@@ -49,6 +49,7 @@ SIGNATURES = {
     "basd_grassmann_distance": [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp],
     "basd_selector_tail": [vp] * 10 + [i32, i32, i32, i32] + [vp] * 14 + [vp],
     "basd_sqrt_clamp": [vp, vp, i64, vp],
+    "basd_gram_finish": [vp, vp, i32, i32, i64, vp, vp, vp],
     "basd_cross_entropy": [vp, i32, i64, i32, i32, vp, vp, i64, f32, i64, vp, vp, vp],
     "basd_token_weights": [vp, i32, vp, i32, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp,
                            vp, vp, vp, vp, vp, vp],

@@ -338,14 +338,30 @@ class _GrassmannDistance(torch.autograd.Function):
     @staticmethod
     def forward(ctx, selector, keys, teachers, *students):
         want_grad = any(s.requires_grad for s in students)
+        # the student side (E Grams + eigen-solves) is independent of the teacher side (2L) and may take its own stream,
+        # joined where the cosine matrices need both.  OFF by default: at cfg-4 the two shared tridiagonalisation stages
+        # side by side cost more than queueing them behind each other (63.7 vs 58.3 ms per step)
+        ss = selector._student_side_stream(students[0].device) if selector.overlap_student_side else None
+
+        def run():
+            if ss is not None:
+                ss.wait_stream(torch.cuda.current_stream())
+                for s in students:
+                    s.record_stream(ss)
+            spectra = selector._spectra_async(list(students), teachers, all_student_vectors=want_grad, student_stream=ss,
+                                              gate_student=False)
+            out = selector._angles_from_spectra(spectra, keys, want_grad=want_grad)
+            if ss is not None:
+                # allocated on the student stream, kept for the backward on this one
+                _record_stream([spectra.get("s_ts"), spectra.get("means"), spectra.get("s_stack"),
+                                spectra.get("s_colnorm"), out[1]], torch.cuda.current_stream())
+            return out
         try:
-            spectra = selector._spectra_async(list(students), teachers, all_student_vectors=want_grad)
-            d, saved = selector._angles_from_spectra(spectra, keys, want_grad=want_grad)
+            d, saved = run()
         except TridiagGiveUp as exc:       # degrade, do not die: once more with one workgroup per matrix
             _single_member_mode(str(exc))
             torch.cuda.synchronize(students[0].device)
-            spectra = selector._spectra_async(list(students), teachers, all_student_vectors=want_grad)
-            d, saved = selector._angles_from_spectra(spectra, keys, want_grad=want_grad)
+            d, saved = run()
         ctx.saved = saved
         ctx.selector = selector
         ctx.n_students = len(students)
@@ -436,6 +452,9 @@ class GrassmannianLayerSelector(nn.Module):
         self._subspace_ranks: dict[int, int] = {}
         self._pending_tail = None          # deferred rank read-back + selector tail of the latest forward
         self.gate_student_chain = os.environ.get("BASD_STUDENT_GATE", "1") != "0"
+        self.teacher_space_gram = os.environ.get("BASD_TEACHER_SPACE_GRAM", "1") != "0"
+        self.overlap_student_side = os.environ.get("BASD_OVERLAP_STUDENT_SIDE", "0") != "0"    # measured: 63.7 vs 58.3 ms at cfg-4
+        self._student_streams: dict = {}
 
         # Same global-RNG consumption order as the reference (proj_s, then proj_t), on CPU.
         proj_s = torch.empty(student_dim, student_dim)
@@ -494,6 +513,8 @@ class GrassmannianLayerSelector(nn.Module):
         M = B * n_t
         proj_t = self.proj_t.float().contiguous()
         n_u = d_s if M >= d_s else M
+        if (projected is None and n_u == d_s and teachers[0].shape[2] <= 1.5 * d_s and self.teacher_space_gram):
+            return self._teacher_grams_in_teacher_space(teachers)
         zs, sums = projected if projected is not None else self._teacher_projections(teachers)
         if n_u == d_s:
             # uncentred / M and centred Grams of every layer's projected tokens: one symmetric launch,
@@ -505,6 +526,27 @@ class GrassmannianLayerSelector(nn.Module):
             g_u[l] = _uncentred_gram(z)
         g_c, _ = ops.centered_grams(zs, fold=(sums, 0))
         return g_u, g_c, M, None
+
+    def _teacher_grams_in_teacher_space(self, teachers: list[torch.Tensor]):
+        """The same two Grams WITHOUT the projected tokens, for teachers about as wide as the student (ViT teachers:
+        D_t <= 1.5 D_s): z = t P^T is never formed.  One centred Gram per layer in the teacher's own space G_c = t_c^T t_c
+        (lower tiles: 29.6 GF at 25088 x 1024), then P G_c P^T (2.8 GF) = the centred Gram of z, and its uncentred Gram
+        / M = (P G_c P^T + M zbar zbar^T) / M with zbar = P tbar -- an addition, no cancellation.  32 GF per layer
+        instead of 74 (projection 39.5 + two 768^2 Grams of z), and the reference's second projection of every layer
+        (layer_selector.py:135) is not paid either."""
+        d_s, L = self.student_dim, len(teachers)
+        B, n_t, d_t = teachers[0].shape
+        M = B * n_t
+        proj_t = self.proj_t.float().contiguous()
+        g_t, tbar = ops.centered_grams(teachers)                                   # (L, d_t, d_t), (L, d_t)
+        wt = ops.gemm_nt(proj_t, g_t[0], batch=L, b_batch_stride=d_t * d_t, rows=d_s, n_cols=d_t)      # P G_c
+        wt = wt.view(L, d_s, d_t)
+        c = ops.gemm_nt(wt[0], proj_t, batch=L, a_batch_stride=d_s * d_t, rows=d_s, n_cols=d_s).view(L, d_s, d_s)
+        zbar = ops.gemm_nt(tbar, proj_t)                                           # (L, d_s)
+        stack = torch.empty((2 * L, d_s, d_s), device=c.device, dtype=torch.float32)
+        ops._lib.call("basd_gram_finish", c.data_ptr(), zbar.data_ptr(), d_s, L, M, stack.data_ptr(),
+                      stack[L].data_ptr(), ops._stream())
+        return stack[:L], stack[L:], M, stack
 
     @torch.no_grad()
     def _estimate_ranks(self, all_teacher_tokens: dict[int, torch.Tensor]) -> None:
@@ -518,6 +560,12 @@ class GrassmannianLayerSelector(nn.Module):
         for k, r in zip(keys, ranks_dev.tolist()):
             self._subspace_ranks[k] = int(r)
 
+    def _student_side_stream(self, device) -> "torch.cuda.Stream":
+        key = str(device)
+        if key not in self._student_streams:
+            self._student_streams[key] = torch.cuda.Stream(device=device)
+        return self._student_streams[key]
+
     def _proj_s_transposed(self) -> torch.Tensor:
         """proj_s^T, fp32 contiguous; cached (the buffer only changes on load_state_dict / .to())."""
         key = (self.proj_s.data_ptr(), self.proj_s._version, self.proj_s.dtype)
@@ -529,7 +577,8 @@ class GrassmannianLayerSelector(nn.Module):
     # ---- distances + mixing weights ------------------------------------------------------
     @torch.no_grad()
     def _spectra_async(self, students: list[torch.Tensor], teachers: list[torch.Tensor],
-                       all_student_vectors: bool = False, student_stream=None, defer_student: bool = False) -> dict:
+                       all_student_vectors: bool = False, student_stream=None, defer_student: bool = False,
+                       gate_student: bool = True) -> dict:
         """Queue every Gram matrix and eigen-solve of the step; no host sync.
         (layer_selector.py:69-74, :131-138, :86-92)
 
@@ -580,7 +629,7 @@ class GrassmannianLayerSelector(nn.Module):
                     st["s_stack"], st["s_colnorm"] = s_stack, ops.jacobi_onesided(s_stack, d_s)
                 else:
                     s_ts = ops.tridiagonalise(s_stack)
-                    if student_stream is not None:
+                    if student_stream is not None and gate_student:
                         # status word of this factorisation: read by the host one step later (it never waits
                         # for the student chain)
                         st["student_status"] = self._queue_readback([s_ts.err], "student")
@@ -595,7 +644,7 @@ class GrassmannianLayerSelector(nn.Module):
         # chain ~1 ms (rocprofv3: teacher Grams 0.46 ms instead of 0.06, shared stage 0.72 instead of 0.48).  So it is
         # queued BEHIND the teacher chain and gated on an event recorded after that stage -- from there on the teacher
         # factorisation sits in one CU per matrix and no longer cares.
-        gated = student_stream is not None and tri and self.gate_student_chain
+        gated = student_stream is not None and tri and self.gate_student_chain and gate_student
         if not gated:
             student_chain()
 

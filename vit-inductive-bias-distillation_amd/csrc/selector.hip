@@ -69,6 +69,25 @@ __global__ void __launch_bounds__(256) grassmann_distance_kernel(const float* __
     if (tid == 0) d_out[m] = num / den;   // k == 0 -> 0/0 = NaN, as in the reference
 }
 
+// The two Grams of the projected teacher tokens z = t P^T from ONE Gram in the teacher's own space (layer_selector.py:72
+// then :13 / :35, without ever forming z): c = P G_c P^T with G_c the centred Gram of t, zbar = P tbar.
+//   centred   (z - 1 zbar^T)^T (z - 1 zbar^T) = P G_c P^T                      -> out_c (symmetrised: c is a product
+//             of two fp32 GEMMs and only symmetric to round-off)
+//   uncentred z^T z / M = (P G_c P^T + M zbar zbar^T) / M                      -> out_u (an addition: no cancellation)
+// grid = (ceil(n n / 256), L), block = 256.
+__global__ void __launch_bounds__(256) gram_finish_kernel(const float* __restrict__ c, const float* __restrict__ zbar,
+                                                          int n, float m_rows, float* __restrict__ out_u,
+                                                          float* __restrict__ out_c) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)n * n) return;
+    const int l = blockIdx.y, i = (int)(idx / n), j = (int)(idx - (long)i * n);
+    const float* cl = c + (long)l * n * n;
+    const float sym = 0.5f * (cl[(long)i * n + j] + cl[(long)j * n + i]);
+    const float zi = zbar[(long)l * n + i], zj = zbar[(long)l * n + j];
+    out_c[(long)l * n * n + idx] = sym;
+    out_u[(long)l * n * n + idx] = fmaf(m_rows * zi, zj, sym) / m_rows;
+}
+
 // sw[i] = sqrt(max(lambda_i, 0)): singular values of the centred data from Gram eigenvalues.
 __global__ void sqrt_clamp_kernel(const float* __restrict__ in, float* __restrict__ out, long count) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,6 +111,14 @@ int basd_grassmann_distance(const float* colnorm, int stride, const int* k_arr, 
                             const int* sw_index, int items, float* d_out, float* theta_out, hipStream_t stream) {
     BASD_CHECK_ARG(colnorm && k_arr && sw && sw_index && d_out && items > 0 && stride > 0 && stride <= 1024);
     grassmann_distance_kernel<<<items, 256, 0, stream>>>(colnorm, stride, k_arr, sw, sw_stride, sw_index, d_out, theta_out);
+    BASD_RETURN_LAST();
+}
+
+int basd_gram_finish(const float* c, const float* zbar, int n, int batch, long m_rows, float* out_u, float* out_c,
+                     hipStream_t stream) {
+    BASD_CHECK_ARG(c && zbar && out_u && out_c && n > 0 && batch > 0 && m_rows > 0);
+    gram_finish_kernel<<<dim3((unsigned)(((long)n * n + 255) / 256), batch), 256, 0, stream>>>(c, zbar, n, (float)m_rows,
+                                                                                              out_u, out_c);
     BASD_RETURN_LAST();
 }
 

@@ -1962,6 +1962,7 @@ static int tridiag_resident_budget(int n) {
         budget = per_cu * cus / 2;
         if (budget > 128) budget = 128;
     }
+    if (const char* sb = getenv("BASD_TRIDIAG_BUDGET")) budget = atoi(sb);      // experiment hook, read once per n
     cached_budget.store(budget, std::memory_order_relaxed);
     cached_n.store(n, std::memory_order_release);
     return budget;
