@@ -64,8 +64,9 @@ for i, ((t0, tr), marks) in enumerate(zip(host, gpu)):
 if mod._chain_plans:
     for sl in list(mod._chain_plans.values())[0].slots:
         w = sl.mirror.tolist()
-        print("factorisation kernel of the last step in this slot: %.1f us on the 100 MHz clock, %.0f shader cycles -> %.2f GHz"
-              % (w[-2] / 100.0, w[-1] * 16.0, w[-1] * 16.0 / max(w[-2] * 10.0, 1)))
+        if w[-2] > 0:                  # BASD_TRIDIAG_CLOCKS=1 only
+            print("factorisation kernel of the last step in this slot: %.1f us on the 100 MHz clock, %.0f shader cycles -> %.2f GHz"
+                  % (w[-2] / 100.0, w[-1] * 16.0, w[-1] * 16.0 / max(w[-2] * 10.0, 1)))
 period = (host[-1][0] - host[5][0]) / (len(host) - 6) * 1e6
 print("%9.1f us  == next step's forward entry (the period)" % period)
 rows = sorted(((sum(v) / len(v), k) for k, v in acc.items()))
