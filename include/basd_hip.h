@@ -214,7 +214,9 @@ int basd_sqrt_clamp(const float* in, float* out, long count, hipStream_t stream)
 /* Both Grams of the projected teacher tokens z = tokens proj_t^T (layer_selector.py:72 -> :13 and :35) from the centred
  * Gram of the tokens in THEIR OWN space, for teachers about as wide as the student (D_t <~ 1.5 D_s: ViT teachers) -- z is
  * never formed: c (batch, n, n) = proj_t G_c proj_t^T (two basd_gemm_nt), zbar (batch, n) = proj_t tbar;
- * out_c = sym(c) (the centred Gram of z), out_u = (sym(c) + M zbar zbar^T) / M (its uncentred Gram / M, M = m_rows). */
+ * out_c (nullable: c is symmetric already) = sym(c) (the centred Gram of z), out_u = (sym(c) + M zbar zbar^T) / M (its
+ * uncentred Gram / M, M = m_rows).  Also the second Gram of basd_selector_chain: c = the centred Gram of the projected
+ * tokens themselves, zbar their column means -- one symmetric launch per layer instead of two. */
 int basd_gram_finish(const float* c, const float* zbar, int n, int batch, long m_rows, float* out_u, float* out_c,
                      hipStream_t stream);
 
@@ -230,9 +232,21 @@ int basd_selector_tail(const float* t_d, const float* t_e, const float* t_tau, c
                        float* v_s, float* z_t, float* u_t, float* u_rot, float* sw, float* cos, int* k_arr,
                        const int* sw_index, float* sigma, int* flags, float* d_out, hipStream_t stream);
 
+/* basd_tridiag_ranked queued BEFORE its input exists (orders 257..384, the one-kernel factorisation; BASD_EUNSUPPORTED
+ * otherwise): its whole-CU workgroups take their CUs while the chip is still quiet and wait, asleep and bounded, until
+ * *go_flag == go_value; set that word with basd_flag_set on the stream that produces the matrices, behind them.  If the
+ * word does not arrive within go_budget polls of ~1.7 us (e.g. a profiler serialising kernels) the workgroups give up:
+ * status word 0 = 2 (also in host_mirror[rank_count]); queue the plain basd_tridiag_ranked then.
+ * replaces: the same call sites as basd_tridiag_ranked (layer_selector.py:16-19, :72-74). */
+int basd_tridiag_ranked_gated(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
+                              void* work, int rank_count, double factor, int cap, int* rank_out, int* host_mirror,
+                              const unsigned* go_flag, unsigned go_value, int go_budget, hipStream_t stream);
+int basd_flag_set(unsigned* flag, unsigned value, hipStream_t stream);
+
 /* The selector of one loss step queued by ONE call over three streams (layer_selector.py:69-74 `_estimate_ranks`,
  * :131-138 teacher subspaces, :86-105 `_mix_for_student_layer` up to d_grass_sq): teacher projections z_l =
- * tokens_l proj_t^T, uncentred / M and centred Grams of every z_l, centred Grams of the E student layers, the
+ * tokens_l proj_t^T, the centred Gram of every z_l and its uncentred Gram / M from it (+ M zbar zbar^T: an addition, no
+ * second symmetric launch), centred Grams of the E student layers, the
  * Householder tridiagonalisation of all 2L + E matrices with the Marchenko-Pastur ranks of the L uncentred ones
  * written to `ranks` (device) and `host_mirror` (pinned host: L ranks + the 8 status words of basd_tridiag_ranked)
  * by the kernel that finishes the factorisation, then -- on tail_stream, with the ranks taken from DEVICE memory --
@@ -245,16 +259,17 @@ int basd_selector_tail(const float* t_d, const float* t_e, const float* t_tau, c
  *             teacher's projections);
  *         1 = teacher matrices first; the student side (Grams + factorisation, student_stream != chain_stream) is
  *             held back until the ranks are out;   2 = the same, not held back;
- *         3 = the same, held back until the teacher's Grams are done (ev_tgram): the student Grams -- the largest MFMA
- *             launch of the step -- then run beside the teacher's factorisation (two CUs) instead of beside its
- *             projection and Grams.
+ *         3 = the same, held back until the teacher's Grams are done (ev_tg0) plus `release_delay` rounds of ~3.4 us:
+ *             the student Grams -- the largest MFMA launch of the step -- then run beside the teacher's
+ *             factorisation (two CUs) instead of beside its projection and Grams, and that factorisation's whole-CU
+ *             workgroups have been placed before the student side's launches refill every free slot.
  *   streams: main_stream = the caller's (inputs are ready there; NULL: the caller has recorded ev_fork on it already,
  *         e.g. before it queued other work the chain need not wait for); events are opaque handles of basd_event_create:
- *         ev_fork / ev_student / ev_ranks / ev_tail / ev_tgram are recorded by the call; ev_slot_free (nullable) is waited for
+ *         ev_fork / ev_student / ev_ranks / ev_tail / ev_tgram / ev_tg0 are recorded by the call; ev_slot_free (nullable) is waited for
  *         before anything is written: the ev_tail of the call that used these buffers last.
  *   Every field is 8 bytes wide.  Device buffers (floats unless noted), n = d_s, M_t = B n_t, nt = ceil(M_t / 128):
- *         z (L, M_t, n); z_sums (L, nt, n); z_ptrs: device table of 2L pointers [z_0..z_{L-1}, z_0..z_{L-1}];
- *         t_scales (2L): 1/M_t x L then 1 x L; t_slabs (2L t_splits n n), t_splits = basd_syrk_splits(M_t, n, 2L);
+ *         z (L, M_t, n); z_sums (L, nt, n); z_means (L, n); z_ptrs: device table of L pointers [z_0..z_{L-1}];
+ *         t_slabs (L t_splits n n), t_splits = basd_syrk_splits(M_t, n, L);
  *         s_partial (E s_parts n), s_parts = basd_colmean_parts(B n_s); s_means (E, n); s_slabs (E s_splits n n);
  *         grams, vh (2L + E, n, n); d, e, tau, vals (2L + E, n); tri_work: basd_tridiag_workspace_bytes(n, 2L + E)
  *         bytes (modes 1, 2: (n, 2L) and tri_work_s (n, E)); ranks (L ints);
@@ -274,7 +289,7 @@ typedef struct BasdSelectorChain {
     double mp_factor;                      /* (1 + sqrt(d_s / M_t))^2, float64 on the host as layer_selector.py:11,18 */
     long rank_cap;                         /* d_s - 1 (layer_selector.py:74) */
     long kmax, kmax_cap, mode;
-    float* z; float* z_sums; const void* const* z_ptrs; const float* t_scales; float* t_slabs; long t_splits;
+    float* z; float* z_sums; const void* const* z_ptrs; float* z_means; float* t_slabs; long t_splits;
     float* s_partial; float* s_means; float* s_slabs; long s_splits, s_parts;
     float* grams; float* d; float* e; float* tau; float* vh; float* vals; void* tri_work; void* tri_work_s;
     int* ranks; int* host_mirror;          /* host_mirror: pinned host memory, L + 8 ints (nullable) */
@@ -282,7 +297,12 @@ typedef struct BasdSelectorChain {
     float* zv; float* vecs; float* u_rot; float* sw; float* cos; float* sigma; float* d_out;
     int* k_arr; const int* sw_index; int* jflags;
     hipStream_t main_stream, chain_stream, student_stream, tail_stream;
-    void* ev_fork; void* ev_student; void* ev_ranks; void* ev_tail; void* ev_slot_free; void* ev_tgram;
+    void* ev_fork; void* ev_student; void* ev_ranks; void* ev_tail; void* ev_slot_free; void* ev_tgram; void* ev_tg0;
+    long release_delay;                    /* mode 3: rounds of ~3.4 us between the teacher's factorisation launch and the student side's release */
+    /* mode 3, nullable: the teacher's factorisation is queued FIRST, on fact_stream, and waits for go_flag (one device
+     * word of the slot, set behind the teacher Grams to go_value != 0): see basd_tridiag_ranked_gated.  ev_ranks is then
+     * recorded on fact_stream. */
+    hipStream_t fact_stream; unsigned* go_flag; long go_value; long go_budget;
     /* measurement (all nullable; timed events of basd_event_create_timed, recorded on the stream of the launch they
      * bracket): tm_proj = behind the projections, tm_tgram = behind the teacher Grams, tm_scol0 / tm_scol1 = around the
      * student column means, tm_sgram = behind the student Grams, tm_tri0 = in front of the factorisation (ev_ranks ends
@@ -470,6 +490,8 @@ int basd_stream_wait_event(hipStream_t stream, void* event);
 int basd_event_record(void* event, hipStream_t stream);
 int basd_event_synchronize(void* event);      /* blocks the calling host thread */
 int basd_event_query(void* event);            /* 1 = reached, 0 = not yet, < 0 = invalid */
+/* A stream of priority level -1 (highest of the device's range), 0 (default) or +1 (lowest). */
+int basd_stream_create_priority(void** out, int level);
 /* diagnostics: events that carry a time stamp (basd_event_create makes them without), and the time between two */
 int basd_event_create_timed(void** out);
 int basd_event_elapsed_ms(void* from, void* to, float* ms_out);

@@ -296,6 +296,38 @@ def test_principal_angle_distance_single_teacher(golden, chain, monkeypatch):
     np.testing.assert_allclose(_d_grass_sq(mod), g["cnn_d_grass_sq"], rtol=2e-4)
 
 
+def test_early_launched_factorisation_gives_up_cleanly(golden, monkeypatch):
+    """The teacher's factorisation is queued ahead of its input and waits, bounded, for a device word (whole-CU
+    workgroups must take their CUs before the step's throughput launches fill the chip).  With a budget of one poll it
+    must give up, the step must fall back to the plain launch (a warning, not an error) and deliver the reference's
+    ranks, loss and distances; the following steps stay on the plain launch."""
+    from basd_amd import chain
+    monkeypatch.setattr(chain, "EARLY_LAUNCH", True)          # an option (BASD_CHAIN_EARLY=1), off by default
+    g = golden("baseline_scalars.npz")
+    # with its normal budget the early-launched factorisation delivers the same ranks / distances
+    shape = synth.CONFIGS["cfg2"]
+    mod = _module(shape, 0.001)
+    inp = synth.make_inputs(shape, 1234, batch=8, device=DEV, strided=True)
+    for _ in range(3):
+        loss = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
+        assert list(mod.layer_selector.subspace_ranks.values()) == list(g["cfg2_s1234_b8_ranks"])
+        np.testing.assert_allclose(_d_grass_sq(mod), g["cfg2_s1234_b8_d_grass_sq"], rtol=2e-4)
+    assert list(mod._chain_plans.values())[0].early is True
+    monkeypatch.setattr(chain, "EARLY_BUDGET", 1)
+    shape = synth.CONFIGS["cfg2"]
+    mod = _module(shape, 0.001)
+    inp = synth.make_inputs(shape, 1234, batch=8, device=DEV, strided=True)
+    with pytest.warns(RuntimeWarning, match="early-launched factorisation"):
+        loss = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
+    assert list(mod.layer_selector.subspace_ranks.values()) == list(g["cfg2_s1234_b8_ranks"])
+    np.testing.assert_allclose(loss.item(), g["cfg2_s1234_b8_loss"], rtol=1e-4)
+    np.testing.assert_allclose(_d_grass_sq(mod), g["cfg2_s1234_b8_d_grass_sq"], rtol=2e-4)
+    plan = list(mod._chain_plans.values())[0]
+    assert plan.early is False
+    loss2 = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)          # no warning any more
+    np.testing.assert_allclose(loss2.item(), g["cfg2_s1234_b8_loss"], rtol=1e-4)
+
+
 def test_principal_angle_distance_cfg2_full_batch_vs_oracle():
     """The same at the headline size (B = 256, kmax 48, n 384): no reference value exists at this size for d (the golden
     holds the loss), so the oracle's selector is run on the CPU for the same inputs (seconds: it needs the Gram route,

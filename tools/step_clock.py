@@ -58,9 +58,10 @@ for i, ((t0, tr), marks) in enumerate(zip(host, gpu)):
     if i < len(raw):
         for label, ev in raw[i].items():
             try:
-                acc.setdefault("GPU  chain " + label, []).append(chain.elapsed_us(ref_raw, ev) - base)
+                t_us = chain.elapsed_us(ref_raw, ev) - base
             except RuntimeError:
-                pass                      # a mark of a branch that did not run this step
+                continue                  # a mark of a branch that did not run this step
+            acc.setdefault("GPU  chain " + label, []).append(t_us)
 if mod._chain_plans:
     for sl in list(mod._chain_plans.values())[0].slots:
         w = sl.mirror.tolist()

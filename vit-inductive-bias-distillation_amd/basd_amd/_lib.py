@@ -36,6 +36,8 @@ SIGNATURES = {
     "basd_tridiag_tuning": [i32, i32, i32, i32, i32, i32],
     "basd_tridiag": [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp],
     "basd_tridiag_ranked": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp, vp],
+    "basd_tridiag_ranked_gated": [vp, i64, i32, i32, vp, vp, vp, vp, vp, i32, f64, i32, vp, vp, vp, C.c_uint, i32, vp],
+    "basd_flag_set": [vp, C.c_uint, vp],
     "basd_scale_unless_one": [vp, i64, vp, vp, vp],
     "basd_event_create": [vp],
     "basd_event_destroy": [vp],
@@ -94,6 +96,7 @@ SIGNATURES = {
     "basd_event_record": [vp, vp],
     "basd_event_synchronize": [vp],
     "basd_event_query": [vp],
+    "basd_stream_create_priority": [vp, i32],
     "basd_event_create_timed": [vp],
     "basd_event_elapsed_ms": [vp, vp, vp],
 }
@@ -127,12 +130,13 @@ class SelectorChainArgs(C.Structure):
         + [(n, i64) for n in ("E", "L", "B", "n_s", "n_t", "d_s", "d_t")]
         + [("mp_factor", f64)]
         + [(n, i64) for n in ("rank_cap", "kmax", "kmax_cap", "mode")]
-        + [(n, vp) for n in ("z", "z_sums", "z_ptrs", "t_scales", "t_slabs")] + [("t_splits", i64)]
+        + [(n, vp) for n in ("z", "z_sums", "z_ptrs", "z_means", "t_slabs")] + [("t_splits", i64)]
         + [(n, vp) for n in ("s_partial", "s_means", "s_slabs")] + [("s_splits", i64), ("s_parts", i64)]
         + [(n, vp) for n in ("grams", "d", "e", "tau", "vh", "vals", "tri_work", "tri_work_s", "ranks", "host_mirror",
                              "student_status_mirror", "zv", "vecs", "u_rot", "sw", "cos", "sigma", "d_out", "k_arr",
                              "sw_index", "jflags", "main_stream", "chain_stream", "student_stream", "tail_stream",
-                             "ev_fork", "ev_student", "ev_ranks", "ev_tail", "ev_slot_free", "ev_tgram",
+                             "ev_fork", "ev_student", "ev_ranks", "ev_tail", "ev_slot_free", "ev_tgram", "ev_tg0",
+                             "release_delay", "fact_stream", "go_flag", "go_value", "go_budget",
                              "tm_proj", "tm_tgram", "tm_scol0", "tm_scol1", "tm_sgram", "tm_tri0", "tm_mid", "tm_spec")]
     )
 

@@ -15,6 +15,13 @@ import torch
 
 from . import _lib, ops
 
+import os
+
+RELEASE_DELAY = int(os.environ.get("BASD_CHAIN_RELEASE_DELAY", "0"))      # mode 3, rounds of ~3.4 us (BasdSelectorChain.release_delay)
+# mode 3: queue the teacher's factorisation FIRST, on a stream of its own, gated by a device word behind the Grams
+# (basd_tridiag_ranked_gated): its whole-CU workgroups hold their CUs before the step's throughput launches fill the chip
+EARLY_LAUNCH = os.environ.get("BASD_CHAIN_EARLY", "0") == "1"      # measured: ranks 0.3 ms earlier, step 0.1 ms LONGER
+EARLY_BUDGET = 1500        # polls of ~1.7 us before the gated kernel gives up (a profiler serialising kernels)
 SPEC_MARGIN = 8            # eigenvectors computed beyond the previous step's largest rank (the rank may grow a little)
 
 
@@ -52,11 +59,11 @@ class _Slot:
         def buf(count, dtype=f32):
             return torch.empty((int(count),), device=dev, dtype=dtype)
 
-        self.t_splits = _lib.query("basd_syrk_splits", M_t, n, 2 * L)
+        self.t_splits = _lib.query("basd_syrk_splits", M_t, n, L)
         self.s_splits = _lib.query("basd_syrk_splits", M_s, n, E)
         self.s_parts = _lib.query("basd_colmean_parts", M_s)
         b = self.bufs = dict(
-            z=buf(L * M_t * n), z_sums=buf(L * tiles * n), t_slabs=buf(2 * L * self.t_splits * n * n),
+            z=buf(L * M_t * n), z_sums=buf(L * tiles * n), z_means=buf(L * n), t_slabs=buf(L * self.t_splits * n * n),
             s_partial=buf(E * self.s_parts * n), s_means=buf(E * n), s_slabs=buf(E * self.s_splits * n * n),
             grams=buf(nmat * n * n), d=buf(nmat * n), e=buf(nmat * n), tau=buf(nmat * n), vh=buf(nmat * n * n),
             vals=buf(nmat * n), ranks=buf(L, i32),
@@ -67,12 +74,13 @@ class _Slot:
         split = p.mode != 0
         b["tri_work"] = buf(_lib.query("basd_tridiag_workspace_bytes", n, 2 * L if split else nmat), torch.uint8)
         b["tri_work_s"] = buf(_lib.query("basd_tridiag_workspace_bytes", n, E), torch.uint8) if split else None
-        b["z_ptrs"] = torch.tensor([b["z"].data_ptr() + 4 * l * M_t * n for l in range(L)] * 2, dtype=torch.int64).to(dev)
-        b["t_scales"] = torch.tensor([1.0 / M_t] * L + [1.0] * L, dtype=f32).to(dev)
+        b["z_ptrs"] = torch.tensor([b["z"].data_ptr() + 4 * l * M_t * n for l in range(L)], dtype=torch.int64).to(dev)
         b["sw_index"] = torch.tensor(list(range(L)) * E, dtype=i32).to(dev)
+        b["go_flag"] = torch.zeros((1,), device=dev, dtype=i32)
+        self.go_value = 0
         self.mirror = torch.zeros((L + 8,), dtype=i32).pin_memory()
         self.student_mirror = torch.zeros((8,), dtype=i32).pin_memory() if split else None
-        self.ev_fork, self.ev_student, self.ev_ranks, self.ev_tail, self.ev_tgram = (_event() for _ in range(5))
+        self.ev_fork, self.ev_student, self.ev_ranks, self.ev_tail, self.ev_tgram, self.ev_tg0 = (_event() for _ in range(6))
         self.used = False                   # ev_tail has been recorded at least once
         self.student_status_pending = False
         self.teacher_ptrs = (C.c_void_p * L)()
@@ -84,7 +92,7 @@ class _Slot:
         a.mp_factor = (1 + (n / M_t) ** 0.5) ** 2          # float64 on the host, as layer_selector.py:11,18
         a.rank_cap, a.kmax_cap, a.mode = n - 1, K, p.mode
         a.t_splits, a.s_splits, a.s_parts = self.t_splits, self.s_splits, self.s_parts
-        for name in ("z", "z_sums", "z_ptrs", "t_scales", "t_slabs", "s_partial", "s_means", "s_slabs", "grams", "d", "e",
+        for name in ("z", "z_sums", "z_ptrs", "z_means", "t_slabs", "s_partial", "s_means", "s_slabs", "grams", "d", "e",
                      "tau", "vh", "vals", "tri_work", "tri_work_s", "ranks", "zv", "vecs", "u_rot", "sw", "cos", "sigma",
                      "k_arr", "sw_index", "jflags"):
             setattr(a, name, None if b[name] is None else b[name].data_ptr())
@@ -92,6 +100,9 @@ class _Slot:
         a.student_status_mirror = None if self.student_mirror is None else self.student_mirror.data_ptr()
         a.ev_fork, a.ev_student, a.ev_ranks, a.ev_tail = self.ev_fork, self.ev_student, self.ev_ranks, self.ev_tail
         a.ev_tgram = self.ev_tgram
+        a.ev_tg0 = self.ev_tg0
+        a.release_delay = RELEASE_DELAY
+        a.go_budget = EARLY_BUDGET
 
 
 class SelectorChainPlan:
@@ -111,8 +122,11 @@ class SelectorChainPlan:
         B, n_t, _ = t.shape
         return B * n_t >= s.shape[2] and s.shape[2] >= 2 and s.shape[2] <= 1024
 
-    def __init__(self, students, teachers, mode: int, streams):
+    def __init__(self, students, teachers, mode: int, streams, fact_stream=None):
         s, t = students[0], teachers[0]
+        self.fact_stream = fact_stream
+        # the early launch needs the one-kernel factorisation (orders 257..384) and mode 3
+        self.early = bool(EARLY_LAUNCH and fact_stream is not None and mode == 3 and 256 < s.shape[2] <= 384)
         self.E, self.L = len(students), len(teachers)
         self.B, self.n_s, self.d_s = s.shape
         _, self.n_t, self.d_t = t.shape
@@ -161,6 +175,12 @@ class SelectorChainPlan:
         slot.d_out.record_stream(self.tail_stream)
         a.d_out = slot.d_out.data_ptr()
         slot.kmax = a.kmax = self.speculative_kmax()
+        if self.early:
+            slot.go_value = slot.go_value % 0x7FFFFFF0 + 1           # never 0, never the word's previous value
+            a.fact_stream, a.go_flag, a.go_value = (self.fact_stream.cuda_stream, slot.bufs["go_flag"].data_ptr(),
+                                                    slot.go_value)
+        else:
+            a.fact_stream, a.go_flag, a.go_value = None, None, 0
         marks = None
         if TIMING is not None:
             marks = {name: _event(True) for name in TM_NAMES}
@@ -171,8 +191,9 @@ class SelectorChainPlan:
                 setattr(a, name, None)
         _lib.call("basd_selector_chain", C.addressof(a))
         if marks is not None:
-            marks["ranks"] = _event(True)           # behind the factorisation + rank kernel, on the chain stream
-            _lib.call("basd_event_record", marks["ranks"], self.chain_stream.cuda_stream)
+            marks["ranks"] = _event(True)           # behind the factorisation + rank kernel, on the stream it runs on
+            _lib.call("basd_event_record", marks["ranks"],
+                      (self.fact_stream if self.early else self.chain_stream).cuda_stream)
             marks["student_end"] = _event(True)
             _lib.call("basd_event_record", marks["student_end"], self.student_stream.cuda_stream)
             marks["tail_end"] = _event(True)        # behind whatever of the tail this call queued

@@ -1010,6 +1010,7 @@ class BASDLoss(nn.Module):
         self.chain_mode = int(os.environ.get("BASD_CHAIN_MODE", "3"))
         # which of the step's two chains the host queues first: the Procrustes kernels of the caller's stream or the selector
         self.procrustes_first = os.environ.get("BASD_PROCRUSTES_FIRST", "0") == "1"
+        self.student_low_priority = os.environ.get("BASD_STUDENT_LOW_PRIORITY", "1") == "1"
         self._chain_plans: dict = {}
 
     def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
@@ -1129,8 +1130,21 @@ class BASDLoss(nn.Module):
             if len(self._chain_plans) >= 4:         # shapes changed for good (another resolution): drop the old workspaces
                 torch.cuda.synchronize(main.device)
                 self._chain_plans.clear()
-            streams = tuple(self._selector_stream(main.device, i) for i in range(3))
-            plan = self._chain_plans[key] = SelectorChainPlan(students, teachers, self.chain_mode, streams)
+            streams = [self._selector_stream(main.device, i) for i in range(3)]
+            if self.student_low_priority:
+                # the student side is throughput work nothing waits for: the device's LOWEST stream priority (torch only
+                # offers high / default), so that the dispatcher serves the two chains the step waits for first
+                key_s = (str(main.device), "student-low")
+                if key_s not in self._side_streams:
+                    import ctypes
+                    h = ctypes.c_void_p()
+                    with torch.cuda.device(main.device):
+                        ops._lib.call("basd_stream_create_priority", ctypes.byref(h), 1)
+                    self._side_streams[key_s] = torch.cuda.ExternalStream(h.value, device=main.device)
+                streams[1] = self._side_streams[key_s]
+            streams = tuple(streams)
+            plan = self._chain_plans[key] = SelectorChainPlan(students, teachers, self.chain_mode, streams,
+                                                              fact_stream=self._selector_stream(main.device, 3))
         return plan
 
     def _forward_single_teacher(self, student_output, targets, students, keys, teachers, attns, comp):
@@ -1170,6 +1184,16 @@ class BASDLoss(nn.Module):
             nonlocal slot
             ranks, status = plan.read_ranks(slot)
             ops.trace("ranks_read")
+            if status[0] == 2 and plan.early:
+                # the factorisation that was queued ahead of its input gave up waiting for it (kernels serialised by a
+                # profiler, or a device that cannot run it beside the producers): plain launches from now on
+                import warnings
+                warnings.warn("basd_selector_chain: the early-launched factorisation timed out waiting for its input; "
+                              "queueing it behind its input for the rest of this process", RuntimeWarning)
+                plan.early = False
+                torch.cuda.synchronize(main.device)
+                slot = plan.queue(xs, teachers, proj_t, sel._proj_s_transposed(), main.cuda_stream)
+                ranks, status = plan.read_ranks(slot)
             if status[0]:       # (words 6, 7 may carry clock readings: BASD_TRIDIAG_CLOCKS)
                 # workgroups sharing a matrix lost each other (bounded spin): degrade, do not die -- the selector of
                 # THIS step once more with one workgroup per matrix, and keep that setting

@@ -35,6 +35,13 @@ __global__ void chain_k_arr_kernel(const int* __restrict__ ranks, int L, int ite
     }
 }
 
+// A fixed delay (no memory polling: it cannot deadlock, whatever runs or does not run beside it): one wave asleep for
+// ~3.4 us x `rounds` at 2.4 GHz.  Queued at the head of the student side (mode 3), which the teacher's Grams release: the whole-CU factorisation workgroups of the teacher side, released by the same Grams on
+// another stream, get their CUs BEFORE the student side's throughput launches refill every free slot.
+__global__ void chain_delay_kernel(int rounds) {
+    for (int i = 0; i < rounds; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 }  // namespace basd
 
 #define BASD_TRY(call)                \
@@ -65,6 +72,18 @@ int basd_event_synchronize(void* ev) {
     BASD_HIP(hipEventSynchronize((hipEvent_t)ev));
     return BASD_OK;
 }
+// A stream of the given priority relative to the device's range: -1 = highest, 0 = default, +1 = lowest.  (torch offers
+// high and default only; the selector's student side -- throughput launches nothing waits for -- wants the LOWEST, so that
+// the dispatcher serves the chains the step waits for first.)
+int basd_stream_create_priority(void** out, int level) {
+    BASD_CHECK_ARG(out && level >= -1 && level <= 1);
+    int least = 0, greatest = 0;           // numerically: greatest priority <= least priority
+    BASD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int prio = level < 0 ? greatest : (level > 0 ? least : 0);
+    BASD_HIP(hipStreamCreateWithPriority((hipStream_t*)out, hipStreamNonBlocking, prio));
+    return BASD_OK;
+}
+
 // diagnostics (tools/step_clock.py): events that carry a time stamp, and the time between two of them
 int basd_event_create_timed(void** out) {
     BASD_CHECK_ARG(out);
@@ -133,7 +152,7 @@ int basd_selector_chain_tail(const BasdSelectorChain* a, int kmax, int exact_k) 
 
 int basd_selector_chain(const BasdSelectorChain* a) {
     BASD_CHECK_ARG(a && a->teacher_host_ptrs && a->student_ptrs && a->proj_t && a->z && a->z_sums && a->z_ptrs &&
-                   a->t_scales && a->t_slabs && a->s_partial && a->s_means && a->s_slabs && a->grams && a->d && a->e &&
+                   a->z_means && a->t_slabs && a->s_partial && a->s_means && a->s_slabs && a->grams && a->d && a->e &&
                    a->tau && a->vh && a->tri_work && a->ranks && a->ev_fork && a->ev_student && a->ev_ranks && a->ev_tail);
     const int E = (int)a->E, L = (int)a->L, B = (int)a->B, n_s = (int)a->n_s, n_t = (int)a->n_t;
     const int n = (int)a->d_s, d_t = (int)a->d_t, mode = (int)a->mode;
@@ -157,19 +176,32 @@ int basd_selector_chain(const BasdSelectorChain* a) {
         if (ss != cs) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_slot_free, 0));
     }
 
-    // ---- teacher: z_l = tokens_l proj_t^T (+ column sums of every 128-row tile), then both Grams of every layer in one
-    // symmetric launch: [uncentred / M x L, centred x L]                                (layer_selector.py:72, :13, :35)
+    // ---- mode 3 with an early launch: the teacher's factorisation takes its CUs NOW and waits for the Grams' word
+    const bool early = mode == 3 && a->go_flag != nullptr && a->fact_stream != nullptr && a->go_value != 0;
+    if (early) {
+        hipStream_t fs = a->fact_stream;
+        if (a->ev_slot_free) BASD_HIP(hipStreamWaitEvent(fs, (hipEvent_t)a->ev_slot_free, 0));
+        int rc_early = basd_tridiag_ranked_gated(a->grams, nn, n, 2 * L, a->d, a->e, a->tau, a->vh, a->tri_work, L,
+                                                 a->mp_factor, (int)a->rank_cap, a->ranks, a->host_mirror, a->go_flag,
+                                                 (unsigned)a->go_value, (int)a->go_budget, fs);
+        if (rc_early != BASD_OK) return rc_early;
+        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_ranks, fs));
+    }
+    // ---- teacher: z_l = tokens_l proj_t^T (+ column sums of every 128-row tile and the column means folded from them),
+    // the centred Gram of every layer in one symmetric launch (layer_selector.py:35) and the uncentred one / M (:13)
+    // from it: z^T z / M = (G_c + M zbar zbar^T) / M -- an addition (no cancellation), half the MFMA work of two Grams
     for (int l = 0; l < L; ++l)
         BASD_TRY(basd_gemm_nt(a->teacher_host_ptrs[l], (int)a->t_dtype, a->t_sb, a->t_sn, a->t_sd, n_t, 0, a->proj_t, d_t,
                               0, (int)M_t, n, d_t, 1, a->z + (long)l * M_t * n, n, M_t * n, 1.f, nullptr, 0.f,
-                              a->z_sums + (long)l * tiles * n, nullptr, cs));
+                              a->z_sums + (long)l * tiles * n, a->z_means + (long)l * n, cs));
     BASD_MARK(a->tm_proj, cs);
-    BASD_TRY(basd_syrk_multi(a->z_ptrs, BASD_DTYPE_F32, 0, n, 1, 1 << 30, (int)M_t, n, 2 * L, nullptr, a->t_scales,
-                             (int)a->t_splits, a->t_slabs, a->grams, nn, 1, a->z_sums, tiles, L, cs));
+    BASD_TRY(basd_syrk_multi(a->z_ptrs, BASD_DTYPE_F32, 0, n, 1, 1 << 30, (int)M_t, n, L, a->z_means, nullptr,
+                             (int)a->t_splits, a->t_slabs, a->grams + (long)L * nn, nn, 1, nullptr, 0, 0, cs));
+    BASD_TRY(basd_gram_finish(a->grams + (long)L * nn, a->z_means, n, L, M_t, a->grams, nullptr, cs));
     BASD_MARK(a->tm_tgram, cs);
     if (mode == 3) {
-        BASD_CHECK_ARG(a->ev_tgram != nullptr);
-        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_tgram, cs));
+        BASD_CHECK_ARG(a->ev_tg0 != nullptr);
+        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_tg0, cs));
     }
 
     auto student_grams = [&](hipStream_t st) -> int {
@@ -200,12 +232,21 @@ int basd_selector_chain(const BasdSelectorChain* a) {
         // teacher matrices first (the host waits for their ranks); the student side on its own stream, in mode 1 held
         // back until the ranks are out (its Gram launch is the largest MFMA launch of the step)
         BASD_MARK(a->tm_tri0, cs);
-        BASD_TRY(basd_tridiag_ranked(a->grams, nn, n, 2 * L, a->d, a->e, a->tau, a->vh, a->tri_work, L, a->mp_factor,
-                                     (int)a->rank_cap, a->ranks, a->host_mirror, a->tm_mid, cs));
-        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_ranks, cs));
+        if (early) {
+            BASD_TRY(basd_flag_set(a->go_flag, (unsigned)a->go_value, cs));       // behind the Grams: the factorisation may read
+        } else {
+            BASD_TRY(basd_tridiag_ranked(a->grams, nn, n, 2 * L, a->d, a->e, a->tau, a->vh, a->tri_work, L, a->mp_factor,
+                                         (int)a->rank_cap, a->ranks, a->host_mirror, a->tm_mid, cs));
+            BASD_HIP(hipEventRecord((hipEvent_t)a->ev_ranks, cs));
+        }
         BASD_CHECK_ARG(a->tri_work_s != nullptr && ss != cs);
         if (mode == 1) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_ranks, 0));
-        if (mode == 3) BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_tgram, 0));
+        if (mode == 3) {
+            // released by the teacher's Grams like the teacher's factorisation (queued above on `cs`), but a short fixed
+            // delay later: that factorisation's whole-CU workgroups are placed first
+            BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_tg0, 0));
+            if (a->release_delay > 0) basd::chain_delay_kernel<<<1, 64, 0, ss>>>((int)a->release_delay);
+        }
         BASD_TRY(student_grams(ss));
         BASD_TRY(basd_tridiag(a->grams + 2L * L * nn, nn, n, E, a->d + 2L * L * n, a->e + 2L * L * n,
                               a->tau + 2L * L * n, a->vh + 2L * L * nn, a->tri_work_s, ss));

@@ -1086,9 +1086,37 @@ __global__ void __launch_bounds__(64 * PK_WAVES) tridiag_packed_kernel(float* __
                                                                        float* __restrict__ d, float* __restrict__ e,
                                                                        float* __restrict__ tau_out,
                                                                        float* __restrict__ Vh, MpRankOut rk,
-                                                                       int clocks) {
+                                                                       int clocks, const unsigned* go_flag,
+                                                                       unsigned go_value, int go_budget) {
     constexpr int WAVES = PK_WAVES, CH = PK_CH;
     __builtin_amdgcn_s_setprio(3);
+    if (go_flag) {
+        // EARLY LAUNCH (basd_tridiag_ranked_gated): this workgroup was queued before its input exists, so that it has
+        // its CU when the input arrives -- a workgroup that needs every VGPR of a CU is only placed on a CU that has
+        // drained, and once the step's throughput launches are refilling every free slot that takes 0.3 ms.  One lane
+        // polls the word the producer's stream sets behind the input (agent-scope loads: served by L2 / fabric), asleep
+        // in between; the other waves wait at a barrier (no issue slots).  BOUNDED: if the word does not arrive
+        // (kernels serialised by a profiler: the producer cannot run while this kernel does), the workgroup gives up
+        // with status word 0 = 2 and the host queues the plain launch.
+        __shared__ int go_ok;
+        if (threadIdx.x == 0) {
+            int ok = 0;
+            for (int i = 0; i < go_budget; ++i) {
+                if (__hip_atomic_load(go_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == go_value) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(64);
+            }
+            go_ok = ok;
+        }
+        __syncthreads();
+        if (!go_ok) {
+            if (threadIdx.x == 0 && blockIdx.x == 0) {
+                if (rk.status) const_cast<int*>(rk.status)[0] = 2;
+                if (rk.host_mirror) rk.host_mirror[rk.count] = 2;
+            }
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the input was written after this kernel started
+    }
     // diagnostics (BASD_TRIDIAG_CLOCKS=1): how long this workgroup ran, on the constant 100 MHz clock and on the shader
     // clock -- status words 6 and 7, which travel to the host with the ranks, tell a run that WAITED for a free CU from
     // one that was slow
@@ -1998,7 +2026,8 @@ long basd_tridiag_workspace_bytes(int n, int batch) {
 }
 
 static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
-                        void* work, MpRankOut rk, hipStream_t stream, hipEvent_t mid_event = nullptr) {
+                        void* work, MpRankOut rk, hipStream_t stream, hipEvent_t mid_event = nullptr,
+                        const unsigned* go_flag = nullptr, unsigned go_value = 0, int go_budget = 0) {
     BASD_CHECK_ARG(a && d && e && tau && vh && work && n > 1 && batch > 0);
     BASD_CHECK_ARG((((uintptr_t)work) & 15) == 0);
     if (n > 4096) return BASD_EUNSUPPORTED;
@@ -2009,6 +2038,7 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
     const bool tail = g_tuning.tail != 0;
     // orders 257..384: the whole factorisation in one CU's registers (upper triangle): no shared stage at all
     const bool packed = g_tuning.tail == 1 && n > TRI_TAIL_MAX && n <= PK_NMAX;
+    if (go_flag && !packed) return BASD_EUNSUPPORTED;       // only the one-kernel factorisation can be queued early
     const int j_stop = !tail ? n - 1 : (packed ? 0 : (n > TRI_TAIL_MAX ? n - TRI_TAIL_MAX : 0));
     if (j_stop > 0) {
         const bool vec = (n & 3) == 0 && (a_batch_stride & 3) == 0 && (((uintptr_t)a) & 15) == 0;
@@ -2045,7 +2075,7 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
         MpRankOut in_tail = rk;
         if (!fused_rank) in_tail.rank_out = nullptr;
         if (packed)
-            tridiag_packed_kernel<<<batch, 64 * PK_WAVES, 0, stream>>>(a, a_batch_stride, n, d, e, tau, vh, in_tail, g_pk_clocks);
+            tridiag_packed_kernel<<<batch, 64 * PK_WAVES, 0, stream>>>(a, a_batch_stride, n, d, e, tau, vh, in_tail, g_pk_clocks, go_flag, go_value, go_budget);
         else if (g_tuning.tail == 2)      // the four-barrier form (16 waves): kept for the tests that compare the two
             tridiag_tail_kernel<16, 16, 4><<<batch, 1024, 0, stream>>>(a, a_batch_stride, n, j_stop, j_stop > 0 ? pend : nullptr, d, e, tau, vh, in_tail);
         else
@@ -2072,6 +2102,30 @@ int basd_tridiag_ranked(float* a, long a_batch_stride, int n, int batch, float* 
     return tridiag_impl(a, a_batch_stride, n, batch, d, e, tau, vh, work,
                         MpRankOut{rank_out, host_mirror, nullptr, factor, cap, rank_count}, stream,
                         (hipEvent_t)mid_event);
+}
+
+// basd_tridiag_ranked QUEUED BEFORE ITS INPUT EXISTS (orders 257..384 only: BASD_EUNSUPPORTED otherwise): the kernel waits,
+// bounded, until *go_flag == go_value (agent scope) and only then reads the matrices; see tridiag_packed_kernel.  The
+// caller queues this on a stream of its own and sets the word with basd_flag_set on the stream that produces the
+// matrices, behind them.  go_budget: polls of ~1.7 us before the workgroups give up (status word 0 = 2, mirrored).
+int basd_tridiag_ranked_gated(float* a, long a_batch_stride, int n, int batch, float* d, float* e, float* tau, float* vh,
+                              void* work, int rank_count, double factor, int cap, int* rank_out, int* host_mirror,
+                              const unsigned* go_flag, unsigned go_value, int go_budget, hipStream_t stream) {
+    BASD_CHECK_ARG(rank_out && rank_count > 0 && rank_count <= batch && go_flag && go_value != 0 && go_budget > 0);
+    return tridiag_impl(a, a_batch_stride, n, batch, d, e, tau, vh, work,
+                        MpRankOut{rank_out, host_mirror, nullptr, factor, cap, rank_count}, stream, nullptr, go_flag,
+                        go_value, go_budget);
+}
+
+namespace basd {
+__global__ void flag_set_kernel(unsigned* flag, unsigned value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace basd
+int basd_flag_set(unsigned* flag, unsigned value, hipStream_t stream) {
+    BASD_CHECK_ARG(flag);
+    basd::flag_set_kernel<<<1, 1, 0, stream>>>(flag, value);
+    BASD_RETURN_LAST();
 }
 
 // All eigenvalues (descending) of the tridiagonals by Sturm bisection.
