@@ -452,6 +452,10 @@ typedef struct BasdProcrustesArgs {
     /* nullable: basd_jacobi_twopass_workspace_bytes(n, E*B, max_sweeps) bytes; the SVD then takes
      * basd_jacobi_stacked_twopass where that covers the shape */
     void* jac_ws;
+    /* nullable, only read when `raw` is set (gradients through the mixing weights): E*B * 2n*n floats; the transposed
+     * route is then taken where basd_jacobi_plain4_fits(n) and U Sigma is rebuilt here (basd_ustack_from_transposed);
+     * sigma_u: E*B * n floats, the norms of its columns (what the backward pairs with w_stack) */
+    float* w_stack; float* sigma_u;
 } BasdProcrustesArgs;
 int basd_procrustes_forward_fused(const BasdProcrustesArgs* args, hipStream_t stream);
 /* Test / tuning hook: 0 = always the stacked cores [M; L_b] (riding rows); 1 = the transposed cores where they apply
@@ -468,6 +472,19 @@ int basd_stack_product_t(const double* la, const double* lb, long l_batch_stride
 int basd_kprime_from_transposed(const float* w, long w_batch_stride, const float* sigma, int n, int batch,
                                 const double* lb, long l_batch_stride, int lb_period, float* z, long z_batch_stride,
                                 float* k_prime, hipStream_t stream);
+/* The transposed route for steps whose backward goes through the mixing weights (multi-layer teachers; autograd of
+ * relational.py:47-48 w.r.t. the teacher side reads U Sigma, the top half of the stacked cores: basd_teacher_factor*):
+ * basd_ustack_stash, between basd_stack_product_t and the Jacobi, copies M (row-major, compact at wc) into the unused
+ * bottom half of the stacked buffer w_stack (E*B x 2n*n floats); basd_ustack_from_transposed, behind the Jacobi, forms
+ * M V from it and X = V Sigma (compact at x, what the Jacobi left) in `scratch` (n*n floats per core), makes its columns
+ * orthogonal relative to their own norms with a short one-sided Jacobi (orthogonality was enforced on V Sigma: M V has
+ * U Sigma's columns to tol sigma_max only; sigma_u receives their norms) and places them in the top half, stacked layout.
+ * The backward reads w_stack with sigma_u. */
+int basd_ustack_stash(const float* wc, long wc_batch_stride, int n, int batch, float* w_stack, long w_stack_stride,
+                      hipStream_t stream);
+int basd_ustack_from_transposed(const float* x, long x_batch_stride, const float* sigma, int n, int batch,
+                                float* w_stack, long w_stack_stride, float* scratch, long scratch_batch_stride,
+                                float* sigma_u, int max_sweeps, int* jflags, hipStream_t stream);
 
 /* x *= num / den unless the ratio is exactly 1 (then the launch returns at once): the upstream gradient of a loss that
  * was differentiated for a unit one.  num, den: one fp32 each on the device, den nullable (= 1). */

@@ -296,6 +296,32 @@ def test_principal_angle_distance_single_teacher(golden, chain, monkeypatch):
     np.testing.assert_allclose(_d_grass_sq(mod), g["cnn_d_grass_sq"], rtol=2e-4)
 
 
+@pytest.mark.parametrize("n_s,n_t", [(49, 64), (196, 196)])
+def test_mixing_weight_gradients_on_the_transposed_route(n_s, n_t, monkeypatch):
+    """Multi-layer teachers with >= 128 cores that the plain LDS solver holds (up to 196 tokens: cfg-4) take the
+    transposed route as well: the Jacobi runs on M^T alone and U Sigma -- the one piece of the SVD the backward through
+    the mixing weights reads -- is rebuilt from it (basd_ustack_from_transposed).  Loss, student gradients and the
+    temperature gradients must agree with the stacked cores (riding rows) on the same inputs."""
+    shape = synth.LossShape("mix-t", 32, n_s, 96, 12, n_t, 128, 3, 4, True, 10, r_s=6, r_t=5)
+    out = []
+    for flag in (False, True):
+        monkeypatch.setattr(ops, "TRANSPOSED_MIX_GRAD", flag)
+        mod = _module(shape, 0.01)
+        inp = synth.make_inputs(shape, 21, device=DEV, strided=True)
+        leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
+        loss = mod(inp.logits, inp.targets, leaves, inp.teacher, inp.attn)
+        loss.backward()
+        out.append((loss.item(), [leaves[l].grad.double() for l in mod.token_layers],
+                    mod.layer_selector.log_temperatures.grad.double().cpu().numpy()))
+    (l0, g0, t0), (l1, g1, t1) = out
+    assert abs(l0 - l1) <= 2e-6 * abs(l0), (l0, l1)
+    # (the two routes agree with fp64 to ~1e-5 each on the stand-alone loss: test_relational_all_gradients_at_196_tokens_
+    # vs_fp64; through the selector's principal angles the gradients are held to 2e-3 against the reference elsewhere)
+    for a, b in zip(g0, g1):
+        assert ((a - b).norm() / a.norm()).item() < 1e-3
+    np.testing.assert_allclose(t1, t0, rtol=2e-3, atol=1e-8)
+
+
 def test_early_launched_factorisation_gives_up_cleanly(golden, monkeypatch):
     """The teacher's factorisation is queued ahead of its input and waits, bounded, for a device word (whole-CU
     workgroups must take their CUs before the step's throughput launches fill the chip).  With a budget of one poll it
@@ -655,6 +681,44 @@ def test_relational_all_gradients_past_lds_vs_fp64(n, d_s, d_t, cls):
     for got, want, name in ((gs, rs, "student"), (gt, rt, "teacher"), (ga, ra, "attn")):
         err = ((got.double().cpu() - want).norm() / want.norm()).item()
         assert err < (2e-3 if name == "attn" else 2e-4), (name, err)
+
+
+@pytest.mark.parametrize("route", ["stacked", "transposed"])
+def test_relational_all_gradients_at_196_tokens_vs_fp64(route, monkeypatch):
+    """The same at cfg-4's core size (196 tokens on both sides) on BOTH SVD routes -- the stacked cores with riding rows
+    (two-pass solver) and the transposed cores with U Sigma rebuilt afterwards (what cfg-4 takes at its batch) -- against
+    fp64 autograd: loss, student, teacher and attention gradients."""
+    from basd_amd.losses import geometric_relational_loss
+    from basd_amd import _lib
+    n, d_s, d_t, cls = 196, 96, 128, True
+    gen = torch.Generator().manual_seed(1961)
+    B = 3
+    s = synth.structured(gen, B, n, d_s, 8) + 0.5
+    t = synth.structured(gen, B, n, d_t, 6) - 0.25
+    a = n + 1
+    attn = torch.softmax(torch.randn(B, 2, a, a, generator=gen), dim=-1)
+    s64, t64, a64 = (x.double().requires_grad_(True) for x in (s, t, attn))
+    w = a64[:, :, 0, 1:].mean(1)
+    w = w / w.sum(-1, keepdim=True)
+    w3 = w.unsqueeze(-1)
+    s_w = w3.sqrt() * (s64 - (w3 * s64).sum(1, keepdim=True))
+    t_w = w3.sqrt() * (t64 - (w3 * t64).sum(1, keepdim=True))
+    ref = (s_w.square().sum((1, 2)) + t_w.square().sum((1, 2))
+           - 2 * torch.linalg.svdvals(torch.bmm(s_w.transpose(1, 2), t_w)).sum(-1)).mean()
+    rs, rt, ra = torch.autograd.grad(ref, [s64, t64, a64])
+    monkeypatch.setattr(ops, "TRANSPOSED_MIX_GRAD", "force" if route == "transposed" else False)
+    _lib.call("basd_procrustes_tuning", 2 if route == "transposed" else 0)
+    try:
+        sd, td, ad = (x.to(DEV).requires_grad_(True) for x in (s, t, attn))
+        loss = geometric_relational_loss(sd, td, ad, has_cls_token=cls)
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+        gs, gt, ga = torch.autograd.grad(loss, [sd, td, ad])
+    finally:
+        _lib.call("basd_procrustes_tuning", 1)
+    for got, want, name in ((gs, rs, "student"), (gt, rt, "teacher"), (ga, ra, "attn")):
+        err = ((got.double().cpu() - want).norm() / want.norm()).item()
+        print(route, name, "rel err vs fp64", err)
+        assert err < (2e-3 if name == "attn" else 2e-4), (route, name, err)
 
 
 def test_teacher_factor_tiled_matches_lds_kernel():

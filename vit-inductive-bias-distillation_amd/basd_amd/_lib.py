@@ -77,6 +77,8 @@ SIGNATURES = {
     "basd_jacobi_plain4_fits": [i32],
     "basd_stack_product_t": [vp, vp, i64, i32, i32, i32, vp, i64, vp],
     "basd_kprime_from_transposed": [vp, i64, vp, i32, i32, vp, i64, i32, vp, i64, vp, vp],
+    "basd_ustack_stash": [vp, i64, i32, i32, vp, i64, vp],
+    "basd_ustack_from_transposed": [vp, i64, vp, i32, i32, vp, i64, vp, i64, vp, i32, vp, vp],
     "basd_resample_tokens": [vp, i32, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "basd_resample_tokens_adjoint": [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
     "basd_student_grad": [vp, i32, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp],
@@ -117,7 +119,7 @@ class ProcrustesArgs(C.Structure):
                              "l_all", "W", "sigma", "jflags", "sweeps", "tr_t", "nuc", "loss_b", "k_prime", "h", "dx",
                              "grad_layers", "g_slabs")]
         + [("g_splits", i64)]
-        + [("uw_ce", vp), ("uw_out", vp), ("jac_ws", vp)]
+        + [("uw_ce", vp), ("uw_out", vp), ("jac_ws", vp), ("w_stack", vp), ("sigma_u", vp)]
     )
 
 

@@ -18,6 +18,8 @@ import os
 F32, BF16 = 0, 1
 MAX_SWEEPS = 20
 TWO_PASS_SVD = True      # test hook: False sends cores of 129..196 tokens through the block solver instead
+TRANSPOSED_MIX_GRAD = True   # test hook: False keeps the stacked cores (riding rows) whenever the mixing weights need a gradient;
+                             # "force": the transposed route also for small batches (with basd_procrustes_tuning(2))
 TWO_PASS_LOG_LIMIT = 16 << 30     # bytes of rotation log above which the block solver is used (cfg-4: 1.6 GB per call)
 # Symmetric eigen-solver for the selector's D_s x D_s Grams when only eigenvalues / leading eigenvectors are
 # needed: "tridiag" (Householder + bisection + inverse iteration) or "jacobi" (block one-sided Jacobi).
@@ -601,12 +603,22 @@ class _ProcrustesPlan:
         self.ints = torch.empty((_lib.query("basd_jacobi_workspace_ints", EB, MAX_SWEEPS) + EB,), device=dev,
                                 dtype=torch.int32)
         self.sweeps = self.ints[-EB:] if want_sweeps else None
-        jac_bytes = _lib.query("basd_jacobi_twopass_workspace_bytes", n, EB, MAX_SWEEPS) if TWO_PASS_SVD else 0
+        transposed_mix = bool(need_mix_grad and need_bwd and _lib.query("basd_jacobi_plain4_fits", n)
+                              and (EB >= 128 or TRANSPOSED_MIX_GRAD == "force") and TRANSPOSED_MIX_GRAD)
+        jac_bytes = _lib.query("basd_jacobi_twopass_workspace_bytes", n, EB, MAX_SWEEPS) \
+            if TWO_PASS_SVD and not transposed_mix else 0
         if jac_bytes > TWO_PASS_LOG_LIMIT or (jac_bytes > (256 << 20)
                                               and jac_bytes > torch.cuda.mem_get_info(dev)[0] // 2):
             jac_bytes = 0       # very large batches / little free memory: the block solver needs no log
         self.jac_ws = torch.empty((jac_bytes // 8 + 1,), device=dev, dtype=torch.int64) if jac_bytes > 0 else None
         self.h = torch.empty((E, B, n, d_s), **f32) if want_dx else None
+        # gradients through the mixing weights read U Sigma (the top half of the stacked cores): where the forward takes
+        # the transposed route (cores the plain LDS solver holds), it is rebuilt into this buffer
+        self.w_stack = None
+        self.sigma_u = None
+        if transposed_mix:
+            self.w_stack = torch.empty((EB, n, 2 * n), **f32)
+            self.sigma_u = torch.empty((EB, n), **f32)
         self.host_ptrs = (ctypes.c_void_p * E)()
 
         a = self.args = _lib.ProcrustesArgs()
@@ -628,6 +640,8 @@ class _ProcrustesPlan:
         a.g_slabs = self.g_all[EB + GB:].data_ptr() if g_splits > 1 else None
         a.g_splits = g_splits
         a.jac_ws = _ptr(self.jac_ws)
+        a.w_stack = _ptr(self.w_stack)
+        a.sigma_u = _ptr(self.sigma_u)
 
 
 _PROCRUSTES_PLANS: dict = {}
@@ -719,7 +733,8 @@ def procrustes_forward(students: list[torch.Tensor], teachers: list[torch.Tensor
     mixgrad = None
     if need_mix_grad:
         l_a, g_b = plan.l_all[:EB], plan.g_all[EB:EB + G * B]
-        mixgrad = dict(raw=raw, tc=plan.tc, l_a=l_a, g_b=g_b, W=plan.W, sigma=plan.sigma, omega_e=omega,
+        mixgrad = dict(raw=raw, tc=plan.tc, l_a=l_a, g_b=g_b, W=plan.w_stack if plan.w_stack is not None else plan.W,
+                       sigma=plan.sigma_u if plan.w_stack is not None else plan.sigma, omega_e=omega,
                        teachers=teachers, attns=attns, tok_tab=_ptr_table(teachers), att_tab=_ptr_table(attns),
                        has_cls=has_cls, n_a=n_a, n=n, n_s=n_s, gather=plan.gt, student_taps=plan.tp, attn_taps=plan.atp)
     sweeps = plan.sweeps.clone() if plan.sweeps is not None else None

@@ -178,9 +178,12 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
     // Cores that the plain 4-lane LDS solver takes, when nothing needs U Sigma afterwards (no gradient through the
     // mixing weights): the Jacobi runs on M^T alone -- its columns come out as V Sigma -- and Y = L_b V is formed when K'
     // is (half the rows per pair-step, no two-pass / block solver at cfg-5's 144 tokens).
-    if (a->raw == nullptr && EB <= 65535 && basd_jacobi_plain4_fits(n) &&
+    // With gradients through the mixing weights (a->raw set) the backward reads U Sigma, the top half of the stacked
+    // cores: it is rebuilt from the transposed route's Z afterwards (a->w_stack), so those steps take this route too.
+    if ((a->raw == nullptr || a->w_stack != nullptr) && EB <= 65535 && basd_jacobi_plain4_fits(n) &&
         (g_transposed_cores == 2 || (g_transposed_cores == 1 && EB >= 128))) {
         BASD_TRY(basd_stack_product_t(a->l_all, a->l_all + (long)EB * nn, nn, n, EB, GB, a->W, 2 * nn, st));
+        if (a->raw != nullptr) BASD_TRY(basd_ustack_stash(a->W, 2 * nn, n, EB, a->w_stack, 2 * nn, st));
         BASD_TRY(basd_jacobi_onesided(a->W, 2 * nn, n, n, n, EB, nullptr, a->sigma, n, (int)a->max_sweeps, 0.f,
                                       a->jflags, a->sweeps, st));
         BASD_TRY(basd_procrustes_finalize(a->W, 2 * nn, a->sigma, n, n_s, EB, GB, a->g_all + (long)EB * nn, nn, a->omega,
@@ -189,6 +192,12 @@ int basd_procrustes_forward_fused(const BasdProcrustesArgs* a, hipStream_t st) {
         if (a->k_prime)
             BASD_TRY(basd_kprime_from_transposed(a->W, 2 * nn, a->sigma, n, EB, a->l_all + (long)EB * nn, nn, GB,
                                                  a->W + nn, 2 * nn, a->k_prime, st));
+        if (a->raw != nullptr) {
+            BASD_CHECK_ARG(a->sigma_u != nullptr);
+            // (scratch: the z region behind X, free again once K' has been formed)
+            BASD_TRY(basd_ustack_from_transposed(a->W, 2 * nn, a->sigma, n, EB, a->w_stack, 2 * nn, a->W + nn, 2 * nn,
+                                                 a->sigma_u, (int)a->max_sweeps, a->jflags, st));
+        }
         return procrustes_tail(a, grad_layers_in, E, B, n_s, n, d_s, EB, nn, om_stride, st);
     }
     BASD_TRY(basd_stack_product(a->l_all, a->l_all + (long)EB * nn, nn, n, EB, GB, a->W, 2 * nn, st));

@@ -182,7 +182,7 @@ __device__ __forceinline__ int lds_row(int r, int rows_dot) {
 // the kernel is bound by VALU / LDS issue with every CU holding several matrices, not by the latency of a round.
 // ---------------------------------------------------------------------------
 template <int EPL, int DOT, int LPP = 16>
-__global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W, long batch_stride, int rows_dot,
+__global__ void __launch_bounds__((LPP == 4 && EPL >= 48) ? 512 : 1024) jacobi_lds_kernel(float* __restrict__ W, long batch_stride, int rows_dot,
                                                            int rows_tot, int n_fixed, const int* __restrict__ n_arr,
                                                            int max_sweeps, float tol, float* __restrict__ colnorm,
                                                            int colnorm_stride, int* __restrict__ sweeps_out) {
@@ -190,8 +190,10 @@ __global__ void __launch_bounds__(1024) jacobi_lds_kernel(float* __restrict__ W,
     // half-wave's ds_read_b64 touches 8 different columns, 8 banks each; with the stride 8 x odd the 8 consecutive
     // columns of a round-robin round tile the 64 banks exactly (PMC with + 2: 40 % of the LDS cycles were conflicts).
     // (8 lanes per pair: 4 columns of 16 banks per half-wave, stride 16 x odd.)
-    constexpr int LD = LPP * EPL + (LPP == 4 ? 8 : LPP == 8 ? 16 : 2);
-    static_assert(LPP != 4 || ((LPP * EPL / 8) % 2 == 0), "stride must come out as 8 x odd");
+    // (4 lanes per pair, 4 EPL already 8 x odd -- the 196-row columns of cfg-4's cores, EPL = 50: no padding at all, which
+    // is what lets a 196 x 196 matrix fit one CU's LDS)
+    constexpr int LD = LPP * EPL + (LPP == 4 ? (((LPP * EPL / 8) % 2 == 0) ? 8 : 0) : LPP == 8 ? 16 : 2);
+    static_assert(LPP != 4 || ((LD / 8) % 2 == 1 && LD % 8 == 0), "stride must come out as 8 x odd");
     static_assert(LPP != 8 || ((LPP * EPL / 16) % 2 == 0), "stride must come out as 16 x odd");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int m = blockIdx.x;
@@ -637,12 +639,14 @@ int basd_jacobi_workspace_ints(int batch, int max_sweeps) { return 2 * batch * m
 
 // 1 when basd_jacobi_onesided solves a batch (>= 128) of plain n x n matrices in LDS with 4 lanes per column pair
 // (orders 40..144): the transposed Procrustes cores then need no riding rows (basd_procrustes_forward_fused).
+// column stride (floats) of the plain 4-lane solver for e elements per lane: 4 e, + 8 unless that is 8 x odd already
+static inline size_t plain4_ld(int e) { return 4 * (size_t)e + (((4 * e / 8) % 2 == 0) ? 8 : 0); }
 int basd_jacobi_plain4_fits(int n) {
     const int n_even = (n + 1) & ~1;
-    if (n_even < 40 || n > 144) return 0;
-    static const int p_epl[] = {8, 16, 24, 36};
+    if (n_even < 40 || n > 200) return 0;
+    static const int p_epl[] = {8, 16, 24, 36, 50};
     for (int e : p_epl)
-        if (4 * e >= n) return (size_t)n_even * (4 * e + 8 + 2) * sizeof(float) <= BASD_JACOBI_LDS_LIMIT;
+        if (4 * e >= n) return (size_t)n_even * (plain4_ld(e) + 2) * sizeof(float) <= BASD_JACOBI_LDS_LIMIT;
     return 0;
 }
 
@@ -773,11 +777,11 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
     // ---- LDS-resident, plain square-ish matrices in large batches (the transposed Procrustes cores: no riding rows),
     // 4 lanes per column pair.  Elements per lane: multiples of 4 (column stride 4 EPL + 8 = 8 x odd). ----
     if (!stacked && !n_arr && n_even >= 8 && (lanes == 4 || (lanes == 0 && batch >= 128 && n_even >= 40))) {
-        static const int p_epl[] = {8, 16, 24, 36};
+        static const int p_epl[] = {8, 16, 24, 36, 50};
         int e4 = 0;
         for (int e : p_epl)
             if (4 * e >= rows_tot) { e4 = e; break; }
-        const size_t lds4 = (size_t)n_even * (4 * e4 + 8 + 2) * sizeof(float);
+        const size_t lds4 = (size_t)n_even * (plain4_ld(e4) + 2) * sizeof(float);
         if (e4 && lds4 <= BASD_JACOBI_LDS_LIMIT) {
             int threads = (((n_even / 2) * 4 + 63) / 64) * 64;
             if (threads > 1024) threads = 1024;
@@ -794,7 +798,8 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
                 case 8: LAUNCH_P4(8); break;
                 case 16: LAUNCH_P4(16); break;
                 case 24: LAUNCH_P4(24); break;
-                default: LAUNCH_P4(36); break;
+                case 36: LAUNCH_P4(36); break;
+                default: LAUNCH_P4(50); break;
             }
 #undef LAUNCH_P4
             BASD_RETURN_LAST();

@@ -17,6 +17,7 @@
 //   d nuc / d A' = K' A',   K' = Y Sigma^+ Y^T   (n x n, symmetric PSD)
 // which the finalize kernel emits; the student-token gradient is then a streaming pass.
 #include "basd_common.h"
+#include "../../include/basd_hip.h"
 
 namespace basd {
 
@@ -974,6 +975,74 @@ __global__ void __launch_bounds__(256) kprime_z_kernel(const float* __restrict__
     }
 }
 
+// The top half U Sigma of the stacked cores, which the backward through the mixing weights reads (teacher_factor: Z =
+// L_a U), rebuilt after the TRANSPOSED route -- the riding rows never rode.  X = V Sigma is what the Jacobi on M^T left
+// (compact n x n, column c at c * n); M itself (row-major) was stashed before the Jacobi destroyed it, in the unused
+// BOTTOM half of the stacked buffer (row i of M at Wst + i * 2n + n):
+//   (U Sigma)[i][c] = (M V)[i][c] = sigma_c^-1 sum_r M[i][r] X[r][c]                 (0 for truncated sigma)
+// A product with M, not L_a^T (L_b V): the latter loses ||L_a|| ||L_b|| / ||M|| digits in the small-sigma columns (2.7 %
+// in the teacher-side gradient at 196 tokens, measured), this one has the absolute accuracy eps sigma_max of columns
+// that rode through the rotations.  32 x 32 tiles; grid = (ceil(n/32), ceil(n/32), batch), block = 256.
+__global__ void __launch_bounds__(256) m_stash_kernel(const float* __restrict__ Wc, long wc_batch_stride, int n,
+                                                      float* __restrict__ Wst, long w_batch_stride) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)n * n) return;
+    const int b = blockIdx.y, i = (int)(idx / n), r = (int)(idx - (long)i * n);
+    Wst[(long)b * w_batch_stride + (long)i * 2 * n + n + r] = Wc[(long)b * wc_batch_stride + idx];
+}
+__global__ void __launch_bounds__(256) ustack_from_x_kernel(const float* __restrict__ X, long x_batch_stride,
+                                                            const float* __restrict__ sigma, int n,
+                                                            const float* __restrict__ Wst, long w_batch_stride,
+                                                            float* __restrict__ Out, long out_batch_stride) {
+    __shared__ float mt[32][33], xt[32][33];      // mt[i][r], xt[c][r]
+    __shared__ float red[4];
+    const int b = blockIdx.z, i0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tid = threadIdx.x;
+    const float* sg = sigma + (long)b * n;
+    float smax = 0.f;
+    for (int j = tid; j < n; j += 256) smax = fmaxf(smax, sg[j]);
+    smax = wave_max(smax);
+    if ((tid & 63) == 0) red[tid >> 6] = smax;
+    __syncthreads();
+    smax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float thr = smax * (float)n * 1.1920929e-7f;
+    const float* Xb = X + (long)b * x_batch_stride;
+    const float* Wb = Wst + (long)b * w_batch_stride;
+    float* Ob = Out + (long)b * out_batch_stride;
+    const int tx = tid & 31, ty = tid >> 5;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < n; r0 += 32) {
+        __syncthreads();
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int q = idx >> 5, rr = idx & 31, r = r0 + rr;
+            mt[q][rr] = (i0 + q < n && r < n) ? Wb[(long)(i0 + q) * 2 * n + n + r] : 0.f;
+            xt[q][rr] = (c0 + q < n && r < n) ? Xb[(long)(c0 + q) * n + r] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) {
+            const float mv = mt[tx][rr];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fmaf(mv, xt[ty + 8 * q][rr], acc[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = c0 + ty + 8 * q, i = i0 + tx;
+        if (c < n && i < n) {
+            const float sv = sg[c];
+            Ob[(long)c * n + i] = sv > thr ? acc[q] / sv : 0.f;      // compact, column c at c * n
+        }
+    }
+}
+// compact n x n columns -> the top half of the stacked layout (column c at c * 2n)
+__global__ void __launch_bounds__(256) ustack_place_kernel(const float* __restrict__ Uc, long uc_batch_stride, int n,
+                                                           float* __restrict__ Wst, long w_batch_stride) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)n * n) return;
+    const int b = blockIdx.y, c = (int)(idx / n), i = (int)(idx - (long)c * n);
+    Wst[(long)b * w_batch_stride + (long)c * 2 * n + i] = Uc[(long)b * uc_batch_stride + idx];
+}
+
 __global__ void __launch_bounds__(256) kprime_from_z_kernel(const float* __restrict__ Z, long z_batch_stride, int n,
                                                             float* __restrict__ Kp) {
     __shared__ float za[32][33], zb[32][33];      // [c][a], [c][b]
@@ -1508,6 +1577,33 @@ int basd_kprime_from_transposed(const float* w, long w_batch_stride, const float
     const int nt = (n + 31) / 32;
     kprime_z_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(w, w_batch_stride, sigma, n, lb, l_batch_stride, lb_period, z, z_batch_stride);
     kprime_from_z_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(z, z_batch_stride, n, k_prime);
+    BASD_RETURN_LAST();
+}
+
+// The transposed route for steps whose backward goes through the mixing weights, in two calls around the Jacobi:
+// basd_ustack_stash copies M (row-major, compact at wc + b * wc_batch_stride: what basd_stack_product_t wrote) into the
+// unused bottom half of the stacked buffer; basd_ustack_from_transposed then forms U Sigma = M V from it and the rotated
+// X = V Sigma (same compact place) into the top half, stacked layout: column c at w_stack + b * w_stack_stride + c * 2n.
+int basd_ustack_stash(const float* wc, long wc_batch_stride, int n, int batch, float* w_stack, long w_stack_stride,
+                      hipStream_t stream) {
+    BASD_CHECK_ARG(wc && w_stack && n > 0 && batch > 0 && batch <= 65535 && w_stack_stride >= 2L * n * n);
+    m_stash_kernel<<<dim3((unsigned)(((long)n * n + 255) / 256), batch), 256, 0, stream>>>(wc, wc_batch_stride, n, w_stack, w_stack_stride);
+    BASD_RETURN_LAST();
+}
+int basd_ustack_from_transposed(const float* x, long x_batch_stride, const float* sigma, int n, int batch,
+                                float* w_stack, long w_stack_stride, float* scratch, long scratch_batch_stride,
+                                float* sigma_u, int max_sweeps, int* jflags, hipStream_t stream) {
+    BASD_CHECK_ARG(x && sigma && w_stack && scratch && sigma_u && n > 0 && batch > 0 && batch <= 65535 &&
+                   w_stack_stride >= 2L * n * n && scratch_batch_stride >= (long)n * n);
+    const int nt = (n + 31) / 32;
+    ustack_from_x_kernel<<<dim3(nt, nt, batch), 256, 0, stream>>>(x, x_batch_stride, sigma, n, w_stack, w_stack_stride, scratch, scratch_batch_stride);
+    // M V has the columns of U Sigma to ~tol sigma_max, not to tol sigma_c: orthogonality was enforced on V Sigma.  A
+    // short one-sided Jacobi on M V itself (it starts almost converged: one or two sweeps) makes them orthogonal relative
+    // to their own norms, as columns that rode through the rotations are; sigma_u are their norms.
+    int rc = basd_jacobi_onesided(scratch, scratch_batch_stride, n, n, n, batch, nullptr, sigma_u, n, max_sweeps, 0.f,
+                                  jflags, nullptr, stream);
+    if (rc != BASD_OK) return rc;
+    ustack_place_kernel<<<dim3((unsigned)(((long)n * n + 255) / 256), batch), 256, 0, stream>>>(scratch, scratch_batch_stride, n, w_stack, w_stack_stride);
     BASD_RETURN_LAST();
 }
 
