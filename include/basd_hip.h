@@ -232,6 +232,16 @@ int basd_selector_tail(const float* t_d, const float* t_e, const float* t_tau, c
                        float* v_s, float* z_t, float* u_t, float* u_rot, float* sw, float* cos, int* k_arr,
                        const int* sw_index, float* sigma, int* flags, float* d_out, hipStream_t stream);
 
+/* Marchenko-Pastur ranks of the UNCENTRED Grams from the factorisations of the CENTRED ones (layer_selector.py:13-19 from
+ * the matrices of :35): z^T z = G_c + M zbar zbar^T and G_c = Q T Q^T give z^T z = Q (T + M w w^T) Q^T with w = Q^T zbar
+ * (basd_tridiag_apply_q, transposed), and the eigenvalues of a rank-one modification are COUNTED without another
+ * factorisation: #{below x} = #{negative pivots of T - x I} + [-1/M - w^T (T - x I)^-1 w < 0] - 1, in one fp64 Sturm
+ * recurrence.  A teacher layer then needs one factorisation instead of two.  d, e: (batch, n); w: (batch, n); rho = M;
+ * factor, cap, rank_out, status, host_mirror as basd_tridiag_mp_rank. */
+int basd_tridiag_mp_rank_rank1(const float* d, const float* e, const float* w, int n, int batch, double rho,
+                               double factor, int cap, int* rank_out, const int* status, int* host_mirror,
+                               hipStream_t stream);
+
 /* basd_tridiag_ranked queued BEFORE its input exists (orders 257..384, the one-kernel factorisation; BASD_EUNSUPPORTED
  * otherwise): its whole-CU workgroups take their CUs while the chip is still quiet and wait, asleep and bounded, until
  * *go_flag == go_value; set that word with basd_flag_set on the stream that produces the matrices, behind them.  If the

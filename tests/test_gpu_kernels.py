@@ -385,6 +385,38 @@ def test_tridiag_mp_rank_matches_full_spectrum(dev, n, M):
     assert pin.tolist() == ref[:2].tolist() + [0] * 8
 
 
+@pytest.mark.parametrize("n,M", [(768, 25088), (384, 12544), (100, 300)])
+def test_mp_rank_from_the_centred_factorisation(dev, n, M):
+    """basd_tridiag_mp_rank_rank1: the Marchenko-Pastur rank of the UNCENTRED Gram z^T z / M counted in the basis that
+    tridiagonalises the CENTRED one (z^T z = Q (T + M w w^T) Q^T, w = Q^T zbar; eigenvalues of a rank-one modification
+    counted by one fp64 Sturm recurrence) -- against the rank from the uncentred Gram's own factorisation and against
+    fp64 eigvalsh, for data with a LARGE mean (the rank-one term dominates the spectrum) and with none."""
+    from basd_amd import ops
+    g = torch.Generator().manual_seed(3 * n)
+    grams_c, grams_u, zbars = [], [], []
+    for r, shift in ((5, 3.0), (n // 8, 0.2), (17, 0.0)):
+        z = (torch.randn(M, r, generator=g, dtype=torch.float64) @ torch.randn(r, n, generator=g, dtype=torch.float64)
+             * (4.0 / r ** 0.5) + torch.randn(M, n, generator=g, dtype=torch.float64) + shift)
+        zb = z.mean(0)
+        zc = z - zb
+        grams_c.append((zc.T @ zc).float())
+        grams_u.append((z.T @ z / M).float())
+        zbars.append(zb.float())
+    Gc, Gu, zbar = torch.stack(grams_c).to(dev), torch.stack(grams_u).to(dev), torch.stack(zbars).to(dev)
+    ts = ops.tridiagonalise(Gc.clone())
+    w = ops.tridiag_apply_q(ts, zbar.view(3, 1, n).contiguous(), transpose=True).view(3, n)
+    pin = torch.empty((3 + 8,), dtype=torch.int32, pin_memory=True)
+    got = ops.tridiag_mp_rank_rank1(ts, w, M, n, n - 1, pin)
+    direct = ops.tridiag_mp_rank(ops.tridiag_eigenvalues(Gu.clone()), M, n, cap=n - 1)
+    ev = torch.linalg.eigvalsh(Gu.double().cpu())
+    lam = ev[:, (n - 1) // 2] * (1 + (n / M) ** 0.5) ** 2
+    ref = (ev > lam.unsqueeze(1)).sum(1).clamp(max=n - 1).to(torch.int32)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), ref), (got, ref)
+    assert torch.equal(direct.cpu(), ref), (direct, ref)
+    assert pin.tolist()[:3] == ref.tolist() and not any(pin.tolist()[3:])
+
+
 def _ulp_step(x: np.float32, steps: int) -> np.float32:
     x = np.float32(x)
     for _ in range(abs(steps)):

@@ -46,6 +46,7 @@ SIGNATURES = {
     "basd_tridiag_apply_q": [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp],
     "basd_tridiag_shifted_solve": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "basd_tridiag_mp_rank": [vp, vp, i32, i32, f64, i32, vp, vp, vp, vp, vp],
+    "basd_tridiag_mp_rank_rank1": [vp, vp, vp, i32, i32, f64, f64, i32, vp, vp, vp, vp],
     "basd_tridiag_eigenvectors": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp],
     "basd_mp_rank": [vp, i32, i32, f64, i32, vp, vp, vp],
     "basd_grassmann_distance": [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp],

@@ -453,6 +453,7 @@ class GrassmannianLayerSelector(nn.Module):
         self._pending_tail = None          # deferred rank read-back + selector tail of the latest forward
         self.gate_student_chain = os.environ.get("BASD_STUDENT_GATE", "1") != "0"
         self.teacher_space_gram = os.environ.get("BASD_TEACHER_SPACE_GRAM", "1") != "0"
+        self.rank1_mp = os.environ.get("BASD_RANK1_MP", "1") != "0"
         self.overlap_student_side = os.environ.get("BASD_OVERLAP_STUDENT_SIDE", "0") != "0"    # measured: 63.7 vs 58.3 ms at cfg-4
         self._student_streams: dict = {}
 
@@ -546,6 +547,7 @@ class GrassmannianLayerSelector(nn.Module):
         stack = torch.empty((2 * L, d_s, d_s), device=c.device, dtype=torch.float32)
         ops._lib.call("basd_gram_finish", c.data_ptr(), zbar.data_ptr(), d_s, L, M, stack.data_ptr(),
                       stack[L].data_ptr(), ops._stream())
+        self._teacher_zbar = zbar          # column means of the projected tokens (the rank-one route of the MP rank)
         return stack[:L], stack[L:], M, stack
 
     @torch.no_grad()
@@ -649,6 +651,7 @@ class GrassmannianLayerSelector(nn.Module):
             student_chain()
 
         # ---- teacher side: projection, Grams, eigen-solve, MP ranks ----
+        self._teacher_zbar = None
         g_u, g_c, M, t_stack = self._teacher_grams(teachers, projected)
         ops.gpu_mark("teacher_grams")
         same = t_stack is not None
@@ -656,6 +659,22 @@ class GrassmannianLayerSelector(nn.Module):
         if not same:
             t_stack = g_c
         st["o_c"] = o_c
+        if tri and same and self.rank1_mp and self._teacher_zbar is not None and student_stream is None:
+            # ONE factorisation per teacher layer (the centred Gram's); the MP rank of the uncentred Gram is counted in
+            # its basis as a rank-one modification: z^T z = Q (T + M w w^T) Q^T, w = Q^T zbar (basd_tridiag_mp_rank_rank1)
+            st["o_c"] = 0
+            pin = self._pinned_ints("teacher", L + 8)
+            ts = ops.tridiagonalise(g_c.contiguous())
+            w = ops.tridiag_apply_q(ts, self._teacher_zbar.view(L, 1, d_s).contiguous(), transpose=True)
+            st["t_ts"] = ts
+            st["ranks_dev"] = ops.tridiag_mp_rank_rank1(ts, w.view(L, d_s), M, d_s, d_s - 1, pin)
+            ready = torch.cuda.Event()
+            ready.record()
+            st["rank_ready"] = (pin, ready)
+            ops.tridiag_spectrum(ts)
+            if gated:
+                student_chain()
+            return st
         if tri and same:
             # The host waits for the ranks and for nothing else: they come straight from the tridiagonals of
             # the uncentred Grams (median by multisection + one Sturm count), are copied to pinned memory at

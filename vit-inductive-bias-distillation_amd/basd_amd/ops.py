@@ -348,6 +348,22 @@ def tridiag_mp_rank(ts: TridiagState, M: int, D: int, cap: int, first: int = 0, 
     return out
 
 
+def tridiag_mp_rank_rank1(ts: TridiagState, w: torch.Tensor, M: int, D: int, cap: int,
+                          host_mirror: torch.Tensor | None = None) -> torch.Tensor:
+    """Marchenko-Pastur ranks (int32, device) of Q (T + M w w^T) Q^T for every factorisation of ``ts``: the uncentred
+    Grams of projected tokens from the factorisations of their centred Grams, w = Q^T zbar (batch, n) -- see
+    basd_tridiag_mp_rank_rank1.  ``host_mirror``: pinned int32 tensor of batch + 8 elements (ranks + status words)."""
+    batch, n = ts.d.shape
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.numel() == batch * n
+    factor = (1 + (D / M) ** 0.5) ** 2          # float64 on the host, as reference layer_selector.py:11,18
+    out = torch.empty((batch,), device=ts.d.device, dtype=torch.int32)
+    if host_mirror is not None:
+        assert host_mirror.is_pinned() and host_mirror.dtype == torch.int32 and host_mirror.numel() == batch + 8
+    _lib.call("basd_tridiag_mp_rank_rank1", ts.d.data_ptr(), ts.e.data_ptr(), w.data_ptr(), n, batch, float(M), factor,
+              cap, out.data_ptr(), _ptr(ts.err) if host_mirror is not None else None, _ptr(host_mirror), _stream())
+    return out
+
+
 def tridiag_eigenvalues(G: torch.Tensor) -> TridiagState:
     """G (batch, n, n) symmetric, DESTROYED.  Queues tridiagonalisation + Sturm bisection; no host sync."""
     ts = tridiagonalise(G)

@@ -1822,6 +1822,114 @@ __device__ __forceinline__ void mp_rank_block(const float* dz, const float* ez, 
     if (o.host_mirror && o.status && z == 0 && tid < 8) o.host_mirror[o.count + tid] = o.status[tid];
 }
 
+// ---------------------------------------------------------------------------
+// Marchenko-Pastur rank of T + rho w w^T -- the UNCENTRED Gram in the basis that tridiagonalises the CENTRED one -- from
+// the centred factorisation alone: z^T z = G_c + M zbar zbar^T (layer_selector.py:13 vs :35), G_c = Q T Q^T, so
+// z^T z = Q (T + M w w^T) Q^T with w = Q^T zbar: a teacher layer then needs ONE factorisation instead of two (cfg-4: 24
+// matrices of order 768 instead of 48; the shared stage is L2-bandwidth-bound there: half the time).
+// Counting eigenvalues of a rank-one modification needs no new factorisation: for A = T - x I (LDL^T pivots q_i: the
+// Sturm sequence) the bordered matrix [[A, w], [w^T, -1/rho]] has inertia(A) + inertia(s), s = -1/rho - w^T A^-1 w, and
+// also inertia(-1/rho) + inertia(A + rho w w^T), hence
+//     #{eigenvalues of T + rho w w^T below x} = #{q_i < 0} + [s < 0] - 1,     w^T A^-1 w = sum_i y_i^2 / q_i,  L y = w.
+// Everything in fp64 (inputs are the fp32 d, e, w): next to a tiny pivot y^2 / q passes 1e70, and the sign of s is
+// what is wanted.  Same order statistics and tie policy as mp_rank_block (lower median, float64 factor, threshold
+// rounded to fp32 on the 1 / M scale the reference works on, strict >).  grid = count, block = 1024.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int sturm_count_rank1(const float* __restrict__ dz, const float* __restrict__ ez,
+                                                 const float* __restrict__ wz, int n, double x, double pivmin,
+                                                 double rho) {
+    int cnt = 0;
+    double q = (double)dz[0] - x;
+    if (fabs(q) < pivmin) q = -pivmin;
+    cnt += q < 0.;
+    // (v_rcp_f64: one instruction, ~1 ulp -- an IEEE fp64 division is a ~40-instruction sequence, twice per step)
+    double rq = __builtin_amdgcn_rcp(q);
+    double y = (double)wz[0], acc = y * y * rq;
+    for (int r = 1; r < n; ++r) {
+        const double er = (double)ez[r - 1], l = er * rq;
+        q = ((double)dz[r] - x) - er * l;
+        if (fabs(q) < pivmin) q = -pivmin;
+        cnt += q < 0.;
+        rq = __builtin_amdgcn_rcp(q);
+        y = (double)wz[r] - l * y;
+        acc = fma(y * y, rq, acc);
+    }
+    const double sc = -1. / rho - acc;
+    return cnt + (sc < 0. ? 1 : 0) - 1;
+}
+
+__global__ void __launch_bounds__(1024) tridiag_mp_rank1_kernel(const float* __restrict__ d, const float* __restrict__ e,
+                                                                const float* __restrict__ w, int n, double rho,
+                                                                double factor, int cap, int* __restrict__ rank_out,
+                                                                const int* __restrict__ status,
+                                                                int* __restrict__ host_mirror) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ double red2[2][16];
+    __shared__ float red3[3][16];
+    const int z = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, nwv = nthr >> 6, count = gridDim.x;
+    const float* dz = d + (long)z * n;
+    const float* ez = e + (long)z * n;
+    const float* wz = w + (long)z * n;
+    float lo = 3.4e38f, hi = -3.4e38f, emax = 0.f, w2 = 0.f;
+    for (int i = tid; i < n; i += nthr) {
+        const float di = dz[i];
+        const float el = i > 0 ? fabsf(ez[i - 1]) : 0.f, er = i < n - 1 ? fabsf(ez[i]) : 0.f;
+        lo = fminf(lo, di - el - er);
+        hi = fmaxf(hi, di + el + er);
+        emax = fmaxf(emax, er * er);
+        w2 = fmaf(wz[i], wz[i], w2);
+    }
+    lo = -wave_max(-lo);
+    hi = wave_max(hi);
+    emax = wave_max(emax);
+    w2 = wave_sum(w2);
+    if ((tid & 63) == 0) { red3[0][tid >> 6] = lo; red3[1][tid >> 6] = hi; red3[2][tid >> 6] = emax; red2[0][tid >> 6] = (double)w2; }
+    __syncthreads();
+    double wn2 = 0.;
+    for (int i = 0; i < nwv; ++i) {
+        lo = fminf(lo, red3[0][i]);
+        hi = fmaxf(hi, red3[1][i]);
+        emax = fmaxf(emax, red3[2][i]);
+        wn2 += red2[0][i];
+    }
+    // T + rho w w^T is T plus a positive semi-definite matrix of norm rho |w|^2
+    const double tnorm = fmax(fabs((double)lo), fabs((double)hi)) + rho * wn2;
+    const double eps = 1.1920929e-7;
+    double a = (double)lo - 2. * tnorm * eps * n - 1e-37, b = (double)hi + rho * wn2 + 2. * tnorm * eps * n + 1e-37;
+    const double pivmin = fmax(1.1754944e-38 * fmax((double)emax, 1.), 1e-37);
+    const int k_asc = (n - 1) / 2;                        // lower median, as torch.median
+    for (int it = 0; it < 48; ++it) {
+        const double x = a + (b - a) * ((double)(tid + 1) / (double)(nthr + 1));
+        const bool below = sturm_count_rank1(dz, ez, wz, n, x, pivmin, rho) <= k_asc;
+        double na = below && x > a ? x : a, nb = (!below && x < b) ? x : b;
+        for (int m = 32; m > 0; m >>= 1) {
+            na = fmax(na, __shfl_xor(na, m, 64));
+            nb = fmin(nb, __shfl_xor(nb, m, 64));
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { red2[0][tid >> 6] = na; red2[1][tid >> 6] = nb; }
+        __syncthreads();
+        for (int i = 0; i < nwv; ++i) {
+            na = fmax(na, red2[0][i]);
+            nb = fmin(nb, red2[1][i]);
+        }
+        const bool stalled = !(na > a) && !(nb < b);
+        a = na;
+        b = nb;
+        // the fp32 resolution of the eigenvalue, as the fp32 bisection of mp_rank_block stops at
+        if (stalled || b - a <= 2. * eps * fmax(fabs(a), fabs(b)) + pivmin) break;   // uniform
+    }
+    // the reference works on z^T z / M: median and threshold on that scale, in fp32 like its tensors
+    const float sigma2 = (float)(0.5 * (a + b) / rho);
+    const float lam = (float)((double)sigma2 * factor);
+    const int above = n - sturm_count_rank1(dz, ez, wz, n, (double)lam * rho, pivmin, rho);
+    if (tid == 0) {
+        rank_out[z] = above < cap ? above : cap;
+        if (host_mirror) host_mirror[z] = above < cap ? above : cap;
+    }
+    if (host_mirror && status && z == 0 && tid < 8) host_mirror[count + tid] = status[tid];
+}
+
 __global__ void __launch_bounds__(1024) tridiag_mp_rank_kernel(const float* __restrict__ d, const float* __restrict__ e,
                                                                int n, double factor, int cap,
                                                                int* __restrict__ rank_out, float* __restrict__ thr_out,
@@ -2177,6 +2285,17 @@ int basd_tridiag_mp_rank(const float* d, const float* e, int n, int batch, doubl
     BASD_CHECK_ARG(d && e && rank_out && n > 0 && batch > 0);
     if (n > 8192) return BASD_EUNSUPPORTED;
     tridiag_mp_rank_kernel<<<batch, 1024, 0, stream>>>(d, e, n, factor, cap, rank_out, thr_out, status, host_mirror);
+    BASD_RETURN_LAST();
+}
+
+// MP ranks of the matrices Q_z (T_z + rho w_z w_z^T) Q_z^T from the tridiagonals (d, e) and the vectors w (batch x n, fp32):
+// see tridiag_mp_rank1_kernel.  rho = M (rows of the projected tokens), factor as basd_mp_rank.
+int basd_tridiag_mp_rank_rank1(const float* d, const float* e, const float* w, int n, int batch, double rho,
+                               double factor, int cap, int* rank_out, const int* status, int* host_mirror,
+                               hipStream_t stream) {
+    BASD_CHECK_ARG(d && e && w && rank_out && n > 0 && batch > 0 && rho > 0.);
+    if (n > 8192) return BASD_EUNSUPPORTED;
+    tridiag_mp_rank1_kernel<<<batch, 1024, 0, stream>>>(d, e, w, n, rho, factor, cap, rank_out, status, host_mirror);
     BASD_RETURN_LAST();
 }
 
