@@ -214,8 +214,8 @@ int basd_sqrt_clamp(const float* in, float* out, long count, hipStream_t stream)
 /* Both Grams of the projected teacher tokens z = tokens proj_t^T (layer_selector.py:72 -> :13 and :35) from the centred
  * Gram of the tokens in THEIR OWN space, for teachers about as wide as the student (D_t <~ 1.5 D_s: ViT teachers) -- z is
  * never formed: c (batch, n, n) = proj_t G_c proj_t^T (two basd_gemm_nt), zbar (batch, n) = proj_t tbar;
- * out_c (nullable: c is symmetric already) = sym(c) (the centred Gram of z), out_u = (sym(c) + M zbar zbar^T) / M (its
- * uncentred Gram / M, M = m_rows).  Also the second Gram of basd_selector_chain: c = the centred Gram of the projected
+ * out_c (nullable: c is symmetric already) = sym(c) (the centred Gram of z), out_u (nullable: the rank-one route of the MP
+ * rank, basd_tridiag_mp_rank_rank1, never forms it) = (sym(c) + M zbar zbar^T) / M (its uncentred Gram / M, M = m_rows).  Also the second Gram of basd_selector_chain: c = the centred Gram of the projected
  * tokens themselves, zbar their column means -- one symmetric launch per layer instead of two. */
 int basd_gram_finish(const float* c, const float* zbar, int n, int batch, long m_rows, float* out_u, float* out_c,
                      hipStream_t stream);

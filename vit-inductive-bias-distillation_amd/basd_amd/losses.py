@@ -454,6 +454,7 @@ class GrassmannianLayerSelector(nn.Module):
         self.gate_student_chain = os.environ.get("BASD_STUDENT_GATE", "1") != "0"
         self.teacher_space_gram = os.environ.get("BASD_TEACHER_SPACE_GRAM", "1") != "0"
         self.rank1_mp = os.environ.get("BASD_RANK1_MP", "1") != "0"
+        self.merge_factorisations = os.environ.get("BASD_MERGE_FACTORISATIONS", "1") != "0"   # cfg-4: 46.4 -> ? ms
         self.overlap_student_side = os.environ.get("BASD_OVERLAP_STUDENT_SIDE", "0") != "0"    # measured: 63.7 vs 58.3 ms at cfg-4
         self._student_streams: dict = {}
 
@@ -514,7 +515,7 @@ class GrassmannianLayerSelector(nn.Module):
         M = B * n_t
         proj_t = self.proj_t.float().contiguous()
         n_u = d_s if M >= d_s else M
-        if (projected is None and n_u == d_s and teachers[0].shape[2] <= 1.5 * d_s and self.teacher_space_gram):
+        if projected is None and self._teacher_space_route(teachers):
             return self._teacher_grams_in_teacher_space(teachers)
         zs, sums = projected if projected is not None else self._teacher_projections(teachers)
         if n_u == d_s:
@@ -528,7 +529,11 @@ class GrassmannianLayerSelector(nn.Module):
         g_c, _ = ops.centered_grams(zs, fold=(sums, 0))
         return g_u, g_c, M, None
 
-    def _teacher_grams_in_teacher_space(self, teachers: list[torch.Tensor]):
+    def _teacher_space_route(self, teachers: list[torch.Tensor]) -> bool:
+        B, n_t, d_t = teachers[0].shape
+        return B * n_t >= self.student_dim and d_t <= 1.5 * self.student_dim and self.teacher_space_gram
+
+    def _teacher_grams_in_teacher_space(self, teachers: list[torch.Tensor], centred_out: torch.Tensor | None = None):
         """The same two Grams WITHOUT the projected tokens, for teachers about as wide as the student (ViT teachers:
         D_t <= 1.5 D_s): z = t P^T is never formed.  One centred Gram per layer in the teacher's own space G_c = t_c^T t_c
         (lower tiles: 29.6 GF at 25088 x 1024), then P G_c P^T (2.8 GF) = the centred Gram of z, and its uncentred Gram
@@ -544,10 +549,17 @@ class GrassmannianLayerSelector(nn.Module):
         wt = wt.view(L, d_s, d_t)
         c = ops.gemm_nt(wt[0], proj_t, batch=L, a_batch_stride=d_s * d_t, rows=d_s, n_cols=d_s).view(L, d_s, d_s)
         zbar = ops.gemm_nt(tbar, proj_t)                                           # (L, d_s)
+        self._teacher_zbar = zbar          # column means of the projected tokens (the rank-one route of the MP rank)
+        if centred_out is not None:
+            # only the centred Gram, where the caller wants it (one factorisation launch over teacher + student matrices;
+            # the MP rank comes from basd_tridiag_mp_rank_rank1)
+            assert centred_out.shape == (L, d_s, d_s) and centred_out.is_contiguous()
+            ops._lib.call("basd_gram_finish", c.data_ptr(), zbar.data_ptr(), d_s, L, M, None, centred_out.data_ptr(),
+                          ops._stream())
+            return None, centred_out, M, None
         stack = torch.empty((2 * L, d_s, d_s), device=c.device, dtype=torch.float32)
         ops._lib.call("basd_gram_finish", c.data_ptr(), zbar.data_ptr(), d_s, L, M, stack.data_ptr(),
                       stack[L].data_ptr(), ops._stream())
-        self._teacher_zbar = zbar          # column means of the projected tokens (the rank-one route of the MP rank)
         return stack[:L], stack[L:], M, stack
 
     @torch.no_grad()
@@ -647,6 +659,29 @@ class GrassmannianLayerSelector(nn.Module):
         # queued BEHIND the teacher chain and gated on an event recorded after that stage -- from there on the teacher
         # factorisation sits in one CU per matrix and no longer cares.
         gated = student_stream is not None and tri and self.gate_student_chain and gate_student
+        if (tri and self.rank1_mp and self.merge_factorisations and student_stream is None
+                and self._teacher_space_route(teachers)):
+            # ONE factorisation launch over the L centred teacher Grams and the E student Grams (multi-layer ViT teachers:
+            # a launch over E = 4 matrices of order 768 takes 2.8 ms, over L = 24 5.0 -- both are bound by dependent
+            # steps, not by the number of matrices), one bisection launch over all spectra.  The MP ranks of the
+            # uncentred teacher Grams come from the centred factorisations (rank-one route, below).
+            xs = ops._check_common_layout([ops.as_supported(x) for x in students], "student token tensors")
+            g_all = torch.empty((L + E, d_s, d_s), device=dev, dtype=torch.float32)
+            _, st["means"] = ops.centered_grams(xs, out=g_all[L:])
+            _, _, M, _ = self._teacher_grams_in_teacher_space(teachers, centred_out=g_all[:L])
+            ops.gpu_mark("teacher_grams")
+            st["o_c"] = 0
+            pin = self._pinned_ints("teacher", L + 8)
+            ts = ops.tridiagonalise(g_all)
+            t_ts = ops.tridiag_slice(ts, 0, L)
+            w = ops.tridiag_apply_q(t_ts, self._teacher_zbar.view(L, 1, d_s).contiguous(), transpose=True)
+            st["t_ts"], st["s_ts"] = t_ts, ops.tridiag_slice(ts, L, E)
+            st["ranks_dev"] = ops.tridiag_mp_rank_rank1(t_ts, w.view(L, d_s), M, d_s, d_s - 1, pin)
+            ready = torch.cuda.Event()
+            ready.record()
+            st["rank_ready"] = (pin, ready)
+            ops.tridiag_spectrum(ts)
+            return st
         if not gated:
             student_chain()
 

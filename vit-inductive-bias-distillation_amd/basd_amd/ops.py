@@ -279,6 +279,13 @@ class TridiagState:
     ranks: torch.Tensor | None = None   # Marchenko-Pastur ranks of the leading matrices (``tridiagonalise(mp_rank=)``)
 
 
+def tridiag_slice(ts: TridiagState, first: int, count: int) -> TridiagState:
+    """Factorisations [first, first + count) of a batch as a state of their own (views; the status words are the
+    batch's: one launch factored them all)."""
+    sl = slice(first, first + count)
+    return TridiagState(ts.d[sl], ts.e[sl], ts.tau[sl], ts.vh[sl], ts.vals[sl], ts.err, None)
+
+
 def tridiagonalise(G: torch.Tensor, mp_rank: tuple | None = None) -> TridiagState:
     """G (batch, n, n) symmetric, DESTROYED.  Queues the Householder tridiagonalisation; ``vals`` is allocated but
     not filled (``tridiag_spectrum``).  No host sync.

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) gram_finish_kernel(const float* __restric
     const float sym = 0.5f * (cl[(long)i * n + j] + cl[(long)j * n + i]);
     const float zi = zbar[(long)l * n + i], zj = zbar[(long)l * n + j];
     if (out_c) out_c[(long)l * n * n + idx] = sym;
-    out_u[(long)l * n * n + idx] = fmaf(m_rows * zi, zj, sym) / m_rows;
+    if (out_u) out_u[(long)l * n * n + idx] = fmaf(m_rows * zi, zj, sym) / m_rows;
 }
 
 // sw[i] = sqrt(max(lambda_i, 0)): singular values of the centred data from Gram eigenvalues.
@@ -116,7 +116,7 @@ int basd_grassmann_distance(const float* colnorm, int stride, const int* k_arr, 
 
 int basd_gram_finish(const float* c, const float* zbar, int n, int batch, long m_rows, float* out_u, float* out_c,
                      hipStream_t stream) {
-    BASD_CHECK_ARG(c && zbar && out_u && n > 0 && batch > 0 && m_rows > 0);
+    BASD_CHECK_ARG(c && zbar && (out_u || out_c) && n > 0 && batch > 0 && m_rows > 0);
     gram_finish_kernel<<<dim3((unsigned)(((long)n * n + 255) / 256), batch), 256, 0, stream>>>(c, zbar, n, (float)m_rows,
                                                                                               out_u, out_c);
     BASD_RETURN_LAST();
