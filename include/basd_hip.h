@@ -12,7 +12,7 @@
  *   - return value: 0 = ok, <0 = invalid argument / unsupported shape (BASD_E*), >0 = hipError_t;
  *   - dtype codes: 0 = fp32, 1 = bf16 (inputs only; all arithmetic and outputs are fp32/fp64);
  *   - entry points are re-entrant and keep no global mutable state, with three process-wide test / tuning hooks as the
- *     only exceptions: basd_tridiag_tuning, basd_jacobi_tuning, basd_procrustes_tuning (none is called by the loss).
+ *     only exceptions: basd_tridiag_tuning, basd_jacobi_tuning, basd_jacobi_ordering, basd_procrustes_tuning (none is called by the loss).
  */
 #ifndef BASD_HIP_H
 #define BASD_HIP_H
@@ -110,6 +110,10 @@ int basd_jacobi_plain4_fits(int n);
  * matrices: 4 lanes for n >= 40, 8 for n >= 16 -- fewer instruction issues per matrix round; else one DPP row of 16),
  * 4 / 8 / 16 = forced where the shape allows. */
 int basd_jacobi_tuning(int lanes_per_pair);
+/* Test / tuning hook: ordering of the plain batched solver (no riding rows, batches >= 128 of orders 40..200: the
+ * transposed Procrustes cores) -- 1 (default) = odd-even ordering with the columns held in registers and one column per
+ * pair-step passed through LDS (two 196 x 196 matrices share a CU), 0 = round-robin ordering through LDS. */
+int basd_jacobi_ordering(int odd_even);
 
 int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot, int n, int batch,
                          const int* n_arr, float* colnorm, int colnorm_stride, int max_sweeps, float tol_cos,

@@ -148,6 +148,49 @@ def test_jacobi_lds_invariants(dev, n, rows_dot, rows_tot, batch):
         assert _rel(top.transpose(1, 2) @ bot, top0.transpose(1, 2) @ bot0) < 1e-5
 
 
+@pytest.mark.parametrize("ordering", [1, 0])
+@pytest.mark.parametrize("n,rows,batch", [(49, 49, 130), (50, 50, 128), (144, 144, 130), (196, 196, 132), (195, 196, 128),
+                                          (41, 64, 129), (96, 90, 128), (196, 196, 3)])
+def test_jacobi_plain_batched_orderings(dev, n, rows, batch, ordering):
+    """The plain batched solver (no riding rows: the transposed Procrustes cores) with both orderings -- odd-even with the
+    columns in registers (jacobi_oe_kernel, the default) and round-robin through LDS: singular values against LAPACK
+    (fp64), orthogonality of the live columns, X^T X unchanged (only right rotations were applied), exactly
+    rank-deficient inputs (the centred cores are), odd orders (a zero column pads the line)."""
+    from basd_amd import ops, _lib
+    g = torch.Generator().manual_seed(7 * n + rows)
+    _lib.call("basd_jacobi_ordering", ordering)
+    _lib.call("basd_jacobi_tuning", 4 if batch < 128 else 0)
+    try:
+        w0 = torch.randn(batch, n, rows, generator=g)
+        w0 *= torch.logspace(0, -3, n).view(1, n, 1)
+        # exactly rank-deficient members: rows confined to a subspace of dimension r - 1 / 5
+        for b, r in ((1, min(n, rows) - 1), (2, 5)):
+            basis = torch.randn(r, rows, generator=g)
+            w0[b] = torch.randn(n, r, generator=g) @ basis
+        W = w0.clone().to(dev)
+        sigma, sweeps = ops.jacobi_onesided(W, rows, want_sweeps=True)
+        assert int(sweeps.max()) < ops.MAX_SWEEPS, "did not converge"
+        x0 = w0.double()                                  # column c of the matrix = x0[b, c, :]
+        x = W.double().cpu()
+        sv = torch.linalg.svdvals(x0)
+        k = sv.shape[1]
+        got = sigma.double().cpu().sort(dim=1, descending=True).values[:, :k]
+        assert ((got - sv).abs().max(dim=1).values / sv[:, 0]).max() < 3e-6
+        rest = sigma.double().cpu().sort(dim=1, descending=True).values[:, k:]
+        assert rest.numel() == 0 or float(rest.abs().max()) < 1e-5 * float(sv.max())
+        assert torch.allclose(sigma.double().cpu(), x.norm(dim=2), rtol=2e-6, atol=1e-6 * float(sv.max()))
+        gram = x @ x.transpose(1, 2)
+        nrm = torch.diagonal(gram, dim1=1, dim2=2).sqrt()
+        off = gram - torch.diag_embed(nrm ** 2)
+        live = (nrm > 1e-6 * nrm.amax(dim=1, keepdim=True)).double()
+        cos = off.abs() / (nrm.unsqueeze(2) * nrm.unsqueeze(1)).clamp_min(1e-30) * live.unsqueeze(2) * live.unsqueeze(1)
+        assert cos.max().item() < 5e-6, cos.max().item()
+        assert _rel(x.transpose(1, 2) @ x, x0.transpose(1, 2) @ x0) < 1e-5      # X V V^T X^T = X X^T
+    finally:
+        _lib.call("basd_jacobi_ordering", 1)
+        _lib.call("basd_jacobi_tuning", 0)
+
+
 def test_jacobi_per_matrix_order(dev):
     from basd_amd import ops
     g = torch.Generator().manual_seed(3)

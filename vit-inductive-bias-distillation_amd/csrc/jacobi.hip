@@ -274,6 +274,171 @@ __global__ void __launch_bounds__((LPP == 4 && EPL >= 48) ? 512 : 1024) jacobi_l
 }
 
 // ---------------------------------------------------------------------------
+// Register-resident solver with the odd-even ("brick wall") ordering, for plain matrices (no riding rows) in batches:
+// the transposed Procrustes cores.
+//
+// The round-robin solver above keeps the columns in LDS and every pair-step reads two columns and writes two: at 196
+// rows the matrix fills a CU's LDS (one matrix per CU, all its waves in the same phase: LDS read, rotate, LDS write),
+// and the LDS pipe is what a round costs.  Here the columns sit on a line of seats 0 .. n - 1; even rounds rotate the
+// seats (2g, 2g + 1), odd rounds (2g + 1, 2g + 2), and after every rotation the two columns trade seats.  n rounds are one
+// sweep: every pair meets exactly once (the exchanges of odd-even transposition on a reversed sequence), and the line
+// ends up reversed.  Group g (4 lanes) holds BOTH its columns in registers; from one round to the next it keeps one of
+// them and passes the other to a neighbour through LDS: ONE column written and ONE read per pair-step instead of two
+// and two, and only the even seats ever travel -- the mail slots are half a matrix (78 KB at 196 x 196), so TWO
+// matrices share a CU and one's LDS phase runs under the other's arithmetic.  One barrier per round: a slot is written
+// by the group that read it last.
+//   round e (even): rotate (X = seat 2g, Y = seat 2g + 1); they trade seats; Y (now seat 2g) -> slot g; barrier;
+//                   slot g + 1 -> Y (seat 2g + 2)
+//   round o (odd) : rotate (X = seat 2g + 1, Y = seat 2g + 2); trade; X (now seat 2g + 2) -> slot g + 1; barrier;
+//                   slot g -> X (seat 2g).                          [slot G is never written and stays zero; the last
+//                   group's odd "rotation" with that zero column is the fixed (c, s) = (0, 1): its column moves over]
+// Squared norms and normalisation defects travel with their columns.  After an odd number of sweeps the columns are
+// written back in reversed order (the zero column that pads an odd order then sits where it started and is dropped).
+// ---------------------------------------------------------------------------
+template <int H>
+__device__ __forceinline__ int rotate_regs(f32x2 (&x)[H], f32x2 (&y)[H], float& a, float& b, float& dx, float& dy,
+                                           float tol, float null2, float& norm2_max, bool forced) {
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < H; ++i) acc = __builtin_elementwise_fma(x[i], y[i], acc);
+    const float g = pair_allsum<4>(acc.x + acc.y);
+    norm2_max = fmaxf(norm2_max, fmaxf(a, b));
+    Rot rot{1.f, 0.f, 0.f, 0.f, false, false};
+    if (fminf(a, b) > null2) rot = make_rotation(a, b, g, tol);
+    float c = rot.c, s = rot.s;
+    if (forced) { c = 0.f; s = 1.f; }
+    if (rot.apply || forced) {
+        const f32x2 c2 = {c, c}, s2 = {s, s};
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const f32x2 xi = x[i], yi = y[i];
+            x[i] = __builtin_elementwise_fma(c2, xi, -(s2 * yi));
+            y[i] = __builtin_elementwise_fma(s2, xi, c2 * yi);
+        }
+    }
+    if (forced) {
+        b = a; a = 0.f; dy = dx; dx = 0.f;
+    } else if (rot.apply) {
+        a = fmaxf(a - rot.t * g, 0.f);
+        b = b + rot.t * g;
+        dx += rot.h;
+        dy += rot.h;
+    }
+    return rot.strong ? 3 : (rot.apply ? 1 : 0);
+}
+
+template <int EPL>
+__global__ void __launch_bounds__(512, 4) jacobi_oe_kernel(float* __restrict__ W, long batch_stride, int rows, int n,
+                                                           int max_sweeps, float tol, float* __restrict__ colnorm,
+                                                           int colnorm_stride, int* __restrict__ sweeps_out) {
+    static_assert(EPL % 2 == 0, "row chunks come in pairs");
+    constexpr int H = EPL / 2;
+    constexpr int LD = 4 * EPL + (((4 * EPL / 8) % 2 == 0) ? 8 : 0);   // 8 x odd: see jacobi_lds_kernel
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int m = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int n_even = (n + 1) & ~1, G = n_even / 2;
+    float* mail_n2 = lds + (G + 1) * LD;
+    float* mail_dev = mail_n2 + (G + 1);
+    __shared__ int s_norm2_bits;
+    float* Wm = W + (long)m * batch_stride;
+    const int g = tid >> 2, gl = tid & 3;
+    const bool active = g < G, last = g == G - 1;
+    for (int idx = tid; idx < (G + 1) * (LD + 2); idx += nthr) lds[idx] = 0.f;
+    if (tid == 0) s_norm2_bits = 0;
+
+    f32x2 x[H], y[H];
+    float a = 0.f, b = 0.f, dx = 0.f, dy = 0.f;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const int r = 2 * gl + 8 * i;
+        const int cx = 2 * g, cy = 2 * g + 1;
+        x[i].x = (active && cx < n && r < rows) ? Wm[(long)cx * rows + r] : 0.f;
+        x[i].y = (active && cx < n && r + 1 < rows) ? Wm[(long)cx * rows + r + 1] : 0.f;
+        y[i].x = (active && cy < n && r < rows) ? Wm[(long)cy * rows + r] : 0.f;
+        y[i].y = (active && cy < n && r + 1 < rows) ? Wm[(long)cy * rows + r + 1] : 0.f;
+    }
+    float* slot_lo = lds + (active ? g : 0) * LD + 2 * gl;           // slot g
+    float* slot_hi = lds + (active ? g + 1 : 0) * LD + 2 * gl;       // slot g + 1
+    __syncthreads();
+
+    float null2 = 0.f;
+    int sweep = 0;
+    for (; sweep < max_sweeps && n > 1; ++sweep) {
+        int rotated = 0;
+        float norm2_max = 0.f;
+        if (active) {       // the cached norms, refreshed from the data once per sweep
+            f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                sa = __builtin_elementwise_fma(x[i], x[i], sa);
+                sb = __builtin_elementwise_fma(y[i], y[i], sb);
+            }
+            a = pair_allsum<4>(sa.x + sa.y);
+            b = pair_allsum<4>(sb.x + sb.y);
+        }
+        for (int dr = 0; dr < G; ++dr) {
+            if (active) {
+                rotated |= rotate_regs<H>(x, y, a, b, dx, dy, tol, null2, norm2_max, false);
+#pragma unroll
+                for (int i = 0; i < H; ++i) *(f32x2*)(slot_lo + 8 * i) = y[i];
+                if (gl == 0) { mail_n2[g] = b; mail_dev[g] = dy; }
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < H; ++i) y[i] = *(const f32x2*)(slot_hi + 8 * i);
+                b = mail_n2[g + 1];
+                dy = mail_dev[g + 1];
+                rotated |= rotate_regs<H>(x, y, a, b, dx, dy, tol, null2, norm2_max, last);
+                if (!last) {
+#pragma unroll
+                    for (int i = 0; i < H; ++i) *(f32x2*)(slot_hi + 8 * i) = x[i];
+                    if (gl == 0) { mail_n2[g + 1] = a; mail_dev[g + 1] = dx; }
+                }
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < H; ++i) x[i] = *(const f32x2*)(slot_lo + 8 * i);
+                a = mail_n2[g];
+                dx = mail_dev[g];
+            }
+        }
+        if (active && gl == 0 && norm2_max > 0.f) atomicMax(&s_norm2_bits, __float_as_int(norm2_max));
+        if (!__syncthreads_or(rotated & 2)) {       // the stopping rule of jacobi_lds_kernel
+            ++sweep;
+            break;
+        }
+        null2 = kNull2 * __int_as_float(s_norm2_bits);
+    }
+    if (sweeps_out && tid == 0) sweeps_out[m] = sweep;
+    if (!active) return;
+
+    // exact norms + write back with the accumulated defects folded in; the line is reversed after an odd number of sweeps
+    f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        sa = __builtin_elementwise_fma(x[i], x[i], sa);
+        sb = __builtin_elementwise_fma(y[i], y[i], sb);
+    }
+    const float na = sqrtf(pair_allsum<4>(sa.x + sa.y)), nb = sqrtf(pair_allsum<4>(sb.x + sb.y));
+    const bool rev = sweep & 1;
+    const int cx = rev ? n_even - 1 - 2 * g : 2 * g, cy = rev ? n_even - 2 - 2 * g : 2 * g + 1;
+    if (gl == 0) {
+        if (cx < n) colnorm[(long)m * colnorm_stride + cx] = fmaf(na, dx, na);
+        if (cy < n) colnorm[(long)m * colnorm_stride + cy] = fmaf(nb, dy, nb);
+    }
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const int r = 2 * gl + 8 * i;
+        if (cx < n && r < rows) Wm[(long)cx * rows + r] = fmaf(x[i].x, dx, x[i].x);
+        if (cx < n && r + 1 < rows) Wm[(long)cx * rows + r + 1] = fmaf(x[i].y, dx, x[i].y);
+        if (cy < n && r < rows) Wm[(long)cy * rows + r] = fmaf(y[i].x, dy, y[i].x);
+        if (cy < n && r + 1 < rows) Wm[(long)cy * rows + r + 1] = fmaf(y[i].y, dy, y[i].y);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Two-pass solver for stacked cores [M; L_b] (2n x n) whose 2n rows do not fit LDS while n rows do (n = 144 at cfg-5,
 // 196 at cfg-4: the block solver above moves the matrix through L2 / HBM n_blocks - 1 times per sweep).
 //   pass 1, jacobi_top_logged_kernel: the LDS-resident solver on the top n x n alone, every pair-step's (c, s) written
@@ -670,6 +835,15 @@ int basd_jacobi_tuning(int lanes_per_pair) {
     return BASD_OK;
 }
 
+// Test / tuning hook: ordering of the plain batched solver -- 1 (default) = odd-even, columns in registers
+// (jacobi_oe_kernel); 0 = round-robin through LDS (jacobi_lds_kernel<E, E, 4>).  Process-wide.
+static int g_jacobi_ordering = 1;
+int basd_jacobi_ordering(int odd_even) {
+    if (odd_even != 0 && odd_even != 1) return BASD_EINVAL;
+    g_jacobi_ordering = odd_even;
+    return BASD_OK;
+}
+
 // One-sided Jacobi on `batch` column-major matrices (rows_tot x n, leading dim rows_tot).
 //   n_arr (device, nullable): per-matrix order for square problems (rows = n_arr[m]); the
 //   storage still uses rows_tot / batch_stride of the largest problem.
@@ -770,6 +944,37 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
             jacobi_lds_kernel<20, 20, 8><<<batch, threads, lds8p, stream>>>(W, batch_stride, rows_dot, rows_tot, n, n_arr,
                                                                             max_sweeps, tol, colnorm, colnorm_stride,
                                                                             sweeps_out);
+            BASD_RETURN_LAST();
+        }
+    }
+
+    // ---- register-resident, odd-even ordering: plain matrices in batches (the transposed Procrustes cores) ----
+    if (g_jacobi_ordering == 1 && !stacked && !n_arr && n_even >= 8 && rows_tot == rows_dot &&
+        (lanes == 0 || lanes == 4) && (g_jacobi_lanes == 4 || (batch >= 128 && n_even >= 40))) {
+        static const int o_epl[] = {8, 16, 24, 36, 50};
+        int e4 = 0;
+        for (int e : o_epl)
+            if (4 * e >= rows_tot) { e4 = e; break; }
+        const int G = n_even / 2;
+        const size_t lds_oe = (size_t)(G + 1) * (plain4_ld(e4) + 2) * sizeof(float);
+        const int threads = ((G * 4 + 63) / 64) * 64;
+        if (e4 && threads <= 512 && lds_oe <= BASD_JACOBI_LDS_LIMIT) {
+#define LAUNCH_OE(E)                                                                                                  \
+    do {                                                                                                              \
+        if (lds_oe > 48 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute((const void*)jacobi_oe_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      BASD_JACOBI_LDS_LIMIT);                                                         \
+        jacobi_oe_kernel<E><<<batch, threads, lds_oe, stream>>>(W, batch_stride, rows_tot, n, max_sweeps, tol, colnorm, \
+                                                                colnorm_stride, sweeps_out);                          \
+    } while (0)
+            switch (e4) {
+                case 8: LAUNCH_OE(8); break;
+                case 16: LAUNCH_OE(16); break;
+                case 24: LAUNCH_OE(24); break;
+                case 36: LAUNCH_OE(36); break;
+                default: LAUNCH_OE(50); break;
+            }
+#undef LAUNCH_OE
             BASD_RETURN_LAST();
         }
     }
