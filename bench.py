@@ -417,7 +417,7 @@ def main() -> None:
                 "grad_allreduce_bytes": int(bucket.buffer.numel() * 4),
                 "grad_allreduce": "RCCL all-reduce (mean) per step on the communicator's stream" if world > 1
                 else "none at world size 1 (bucket packed, nothing to exchange)",
-                "rank_readback": "sync" if mod.sync_ranks else "deferred",
+                "rank_readback": mod.rank_readback, "readback_deferred_steps": mod.readback_deferred_steps,
                 "selector": (f"basd_selector_chain mode {mod.chain_mode}" if marks else "kernel by kernel"),
                 "parallelism": f"dp{world}",
             },

@@ -322,8 +322,24 @@ typedef struct BasdSelectorChain {
      * student column means, tm_sgram = behind the student Grams, tm_tri0 = in front of the factorisation (ev_ranks ends
      * it), tm_mid = between its two stages, tm_spec = behind the spectra at the head of the tail */
     void* tm_proj; void* tm_tgram; void* tm_scol0; void* tm_scol1; void* tm_sgram; void* tm_tri0; void* tm_mid; void* tm_spec;
+    /* Rank certificate (all three nullable together).  The reference raises inside forward when a teacher layer has MP
+     * rank 0 (layer_selector.py:16-19 -> NaN weights -> torch.linalg.svd raises), which is what the host waits ~1.5 ms
+     * for.  Behind the teacher Grams -- long before the factorisation -- one small kernel on cert_stream proves
+     * "every rank >= 1" where it can: with eigenvalues l_1 >= ... >= l_n >= 0 of the uncentred Gram G = A + zbar zbar^T,
+     *     l_1 >= max(|zbar|^2, ||G||_F^2 / tr G)   and   median <= min(tr G / c, tr A / (c - 1)),  c = n - (n-1)/2,
+     * so "left > 1.5 factor right" (the 1.5: fp32 eigenvalue errors ~2e-5 l_1, entries slightly off PSD)
+     * leaves no way for l_1 > fp32(median factor) to fail.  cert_mirror (pinned host, 1 int) = 1 if proven for ALL
+     * layers, else 0 (flat spectra, NaN: the caller then waits for the ranks as before); ev_cert is recorded behind it.
+     * cert_stream may be chain_stream (the kernel then sits between the Grams and the factorisation; measured best). */
+    hipStream_t cert_stream; int* cert_mirror; void* ev_cert;
 } BasdSelectorChain;
 int basd_selector_chain(const BasdSelectorChain* args);
+/* The certificate kernel of BasdSelectorChain.cert_mirror on its own: *flag (device or pinned host memory) = 1 iff
+ *     max(|zbar|^2, ||G||_F^2 / tr G) > 1.5 factor min(tr G / c, (tr G - |zbar|^2) / (c - 1)),   c = n - (n-1)/2,
+ * holds for every one of the `batch` symmetric n x n matrices G = A + zbar zbar^T (A PSD; zbar (batch, n) nullable = 0)
+ * -- a sufficient condition for "every Marchenko-Pastur rank (layer_selector.py:16-19) is >= 1"; else 0. */
+int basd_rank_certificate(const float* grams, const float* zbar, int n, int batch, double factor, int* flag,
+                          hipStream_t stream);
 /* exact_k != 0: the caller has READ the ranks and every one of them equals kmax (one teacher layer): the principal-angle
  * matrices then have one common order and may leave LDS (orders past basd_jacobi_lds_square_fits; a speculative kmax
  * past it returns BASD_EUNSUPPORTED). */

@@ -460,6 +460,80 @@ def test_mp_rank_from_the_centred_factorisation(dev, n, M):
     assert pin.tolist()[:3] == ref.tolist() and not any(pin.tolist()[3:])
 
 
+def test_rank_certificate_is_sound(dev):
+    """basd_rank_certificate: flag = 1 must IMPLY that every Marchenko-Pastur rank (fp64 spectrum, lower median, strict
+    '>', layer_selector.py:16-19) is >= 1 -- over flat spectra, barely-separated spikes, heavy tails, one matrix of a
+    batch failing, NaNs; and it must actually fire on spectra like the ones teachers produce (a few dominant directions)."""
+    from basd_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    n, M = 96, 3000
+    factor = (1 + (n / M) ** 0.5) ** 2
+    q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+
+    def gram(ev):
+        return ((q * ev) @ q.T).float()
+
+    def mp_rank(G):
+        ev = torch.linalg.eigvalsh(G.double())
+        lam = ev[(n - 1) // 2] * factor
+        return int((ev > lam).sum())
+
+    spectra = {
+        "flat": torch.ones(n, dtype=torch.float64),
+        "noise": torch.distributions.Chi2(M).sample((n,)).double() / M,
+        "spike_below": torch.cat([torch.tensor([factor * 0.999]), torch.ones(n - 1)]).double(),
+        "spike_just_above": torch.cat([torch.tensor([factor * 1.01]), torch.ones(n - 1)]).double(),
+        "spike_x3": torch.cat([torch.tensor([3.0]), torch.ones(n - 1)]).double(),
+        "spike_x40": torch.cat([torch.tensor([40.0]), torch.ones(n - 1)]).double(),
+        "signal_12": torch.cat([torch.full((12,), 50.0), torch.ones(n - 12)]).double(),
+        "power_law": (torch.arange(1, n + 1, dtype=torch.float64)) ** -1.5,
+        "upper_half_big": torch.cat([torch.full((n // 2 + 2,), 10.0), torch.ones(n - n // 2 - 2)]).double(),
+        "zero": torch.zeros(n, dtype=torch.float64),
+    }
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    fired = {}
+    for name, ev in spectra.items():
+        G = gram(ev).to(dev).contiguous()
+        _lib.call("basd_rank_certificate", G.data_ptr(), None, n, 1, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        fired[name] = int(flag.item())
+        if fired[name]:
+            assert mp_rank(G.cpu()) >= 1, name
+    assert not fired["flat"] and not fired["noise"] and not fired["spike_below"] and not fired["zero"]
+    assert not fired["upper_half_big"]                       # rank 0 by construction (the median is one of the big ones)
+    assert fired["spike_x40"] and fired["signal_12"] and fired["power_law"], fired
+    # random spectra: soundness only
+    for trial in range(40):
+        k = int(torch.randint(0, 8, (1,), generator=g))
+        ev = torch.rand(n, generator=g, dtype=torch.float64) + 0.5
+        ev[:k] *= 10.0 ** float(torch.rand(1, generator=g) * 2)
+        G = gram(ev).to(dev).contiguous()
+        _lib.call("basd_rank_certificate", G.data_ptr(), None, n, 1, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if int(flag.item()):
+            assert mp_rank(G.cpu()) >= 1, (trial, k)
+    # a flat spectrum plus a large mean: only the mean-based bounds can see that (uncentred Grams of features with a mean)
+    zb = torch.randn(n, generator=g, dtype=torch.float64)
+    zb *= 3.0 / zb.norm()
+    for scale, expect in ((1.0, 1), (0.05, 0)):
+        z = (zb * scale).float()
+        G = (gram(torch.ones(n, dtype=torch.float64)).double() + torch.outer(z.double(), z.double())).float().to(dev).contiguous()
+        zd = z.to(dev).contiguous()
+        _lib.call("basd_rank_certificate", G.data_ptr(), zd.data_ptr(), n, 1, factor, flag.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+        assert int(flag.item()) == expect
+        if expect:
+            assert mp_rank(G.cpu()) >= 1
+    # a batch is certified only if EVERY matrix is; NaN never certifies
+    both = torch.stack([gram(spectra["signal_12"]), gram(spectra["flat"])]).to(dev).contiguous()
+    _lib.call("basd_rank_certificate", both.data_ptr(), None, n, 2, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert int(flag.item()) == 0
+    both[1] = both[0]
+    _lib.call("basd_rank_certificate", both.data_ptr(), None, n, 2, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert int(flag.item()) == 1
+    both[1, 3, 5] = float("nan")
+    _lib.call("basd_rank_certificate", both.data_ptr(), None, n, 2, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert int(flag.item()) == 0
+
+
 def _ulp_step(x: np.float32, steps: int) -> np.float32:
     x = np.float32(x)
     for _ in range(abs(steps)):

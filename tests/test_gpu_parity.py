@@ -418,17 +418,22 @@ def test_bf16_inputs_cfg5_shapes():
         assert ((g - r).norm() / r.norm()).item() < 1e-2       # the gradient itself is rounded to bf16
 
 
-@pytest.mark.parametrize("sync_ranks", [True, False])
+@pytest.mark.parametrize("sync_ranks", [True, False, "auto"])
 def test_rank_zero_raises_like_the_reference(sync_ranks):
     """A teacher whose projected Gram has a flat spectrum has Marchenko-Pastur rank 0 (no eigenvalue exceeds
     median * (1 + sqrt(q))^2); the reference then produces NaN mixing weights and torch.linalg.svd raises
     LinAlgError.  Same class here, and the oracle agrees on the rank.
-    ``sync_ranks`` (the default): raised inside the call, the reference's timing; deferred read-back
+    ``rank_readback`` "sync" and "auto" (the default: a flat spectrum is exactly what the rank certificate cannot
+    prove anything about, so the host waits for the ranks): raised inside the call, the reference's timing; "deferred"
     (BASD_RANK_READBACK=deferred, one teacher layer): raised by the first reader of ``subspace_ranks`` or by the
     next forward."""
     shape = synth.LossShape("flat", 4, 16, 32, 12, 16, 48, 1, 1, False, 10)
     mod = _module(shape, 0.0)
-    mod.sync_ranks = sync_ranks
+    if sync_ranks == "auto":
+        assert mod.rank_readback == "auto", "the default"
+        sync_ranks = True
+    else:
+        mod.sync_ranks = sync_ranks
     gen = torch.Generator().manual_seed(1)
     B = 8
     q, _ = torch.linalg.qr(torch.randn(B * 16, 48, generator=gen))      # orthonormal columns: T^T T = I
@@ -450,6 +455,36 @@ def test_rank_zero_raises_like_the_reference(sync_ranks):
         with pytest.raises(torch.linalg.LinAlgError):
             mod.layer_selector.subspace_ranks                      # ... and this step's on the first read
     assert mod.layer_selector.subspace_ranks == {0: 0}
+
+
+def test_rank_readback_is_deferred_only_behind_a_proof():
+    """``rank_readback = "auto"``: with a teacher whose spectrum has a clear signal part the certificate kernel proves
+    "rank >= 1" behind the teacher Grams and forward returns without waiting for the factorisation -- same loss, same
+    gradients, the same ranks and d_grass_sq (read afterwards) as with the read-back inside forward."""
+    shape = synth.CONFIGS["cfg2"]
+    inp = synth.make_inputs(shape, 7, batch=64, device=DEV, strided=True)
+    out = {}
+    for mode in ("sync", "auto"):
+        mod = _module(shape, 0.0)
+        mod.rank_readback = mode
+        leaves = {l: inp.student[l].detach().requires_grad_(True) for l in mod.token_layers}
+        for _ in range(2):       # the second step also exercises the speculative tail behind a deferred read-back
+            for t in leaves.values():
+                t.grad = None
+            loss = mod(inp.logits, inp.targets, leaves, inp.teacher, inp.attn)
+            loss.backward()
+        deferred = mod.readback_deferred_steps
+        ranks = dict(mod.layer_selector.subspace_ranks)              # completes a deferred read-back
+        mod.layer_selector.finish_pending()
+        torch.cuda.synchronize()
+        out[mode] = (loss.item(), [leaves[l].grad.clone() for l in mod.token_layers], ranks,
+                     mod.last_components["d_grass_sq"].clone(), deferred)
+    assert out["sync"][4] == 0 and out["auto"][4] == 2, (out["sync"][4], out["auto"][4])
+    assert out["sync"][0] == out["auto"][0]
+    for a, b in zip(out["sync"][1], out["auto"][1]):
+        assert torch.equal(a, b)
+    assert out["sync"][2] == out["auto"][2] and min(out["auto"][2].values()) >= 1
+    assert torch.equal(out["sync"][3], out["auto"][3])
 
 
 def test_selector_forward_api_materialises_mixed_tensors(golden):

@@ -95,6 +95,7 @@ SIGNATURES = {
     "basd_grassmann_distance_bwd": [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp],
     "basd_eigvec_k2": [vp, vp, i32, i32, i32, vp, vp],
     "basd_selector_chain": [vp],
+    "basd_rank_certificate": [vp, vp, i32, i32, f64, vp, vp],
     "basd_selector_chain_tail": [vp, i32, i32],
     "basd_jacobi_lds_square_fits": [i32],
     "basd_event_record": [vp, vp],
@@ -141,7 +142,8 @@ class SelectorChainArgs(C.Structure):
                              "sw_index", "jflags", "main_stream", "chain_stream", "student_stream", "tail_stream",
                              "ev_fork", "ev_student", "ev_ranks", "ev_tail", "ev_slot_free", "ev_tgram", "ev_tg0",
                              "release_delay", "fact_stream", "go_flag", "go_value", "go_budget",
-                             "tm_proj", "tm_tgram", "tm_scol0", "tm_scol1", "tm_sgram", "tm_tri0", "tm_mid", "tm_spec")]
+                             "tm_proj", "tm_tgram", "tm_scol0", "tm_scol1", "tm_sgram", "tm_tri0", "tm_mid", "tm_spec",
+                             "cert_stream", "cert_mirror", "ev_cert")]
     )
 
 

@@ -22,6 +22,7 @@ RELEASE_DELAY = int(os.environ.get("BASD_CHAIN_RELEASE_DELAY", "0"))      # mode
 # (basd_tridiag_ranked_gated): its whole-CU workgroups hold their CUs before the step's throughput launches fill the chip
 EARLY_LAUNCH = os.environ.get("BASD_CHAIN_EARLY", "0") == "1"      # measured: ranks 0.3 ms earlier, step 0.1 ms LONGER
 EARLY_BUDGET = 1500        # polls of ~1.7 us before the gated kernel gives up (a profiler serialising kernels)
+CERTIFICATE = os.environ.get("BASD_RANK_CERT", "1") != "0"      # the rank certificate kernel (BasdSelectorChain.cert_mirror)
 SPEC_MARGIN = 8            # eigenvectors computed beyond the previous step's largest rank (the rank may grow a little)
 
 
@@ -81,6 +82,8 @@ class _Slot:
         self.mirror = torch.zeros((L + 8,), dtype=i32).pin_memory()
         self.student_mirror = torch.zeros((8,), dtype=i32).pin_memory() if split else None
         self.ev_fork, self.ev_student, self.ev_ranks, self.ev_tail, self.ev_tgram, self.ev_tg0 = (_event() for _ in range(6))
+        self.ev_cert = _event()
+        self.cert_mirror = torch.zeros((8,), dtype=i32).pin_memory()       # [0]: 1 = every rank of this step is >= 1, proven
         self.used = False                   # ev_tail has been recorded at least once
         self.student_status_pending = False
         self.teacher_ptrs = (C.c_void_p * L)()
@@ -102,6 +105,8 @@ class _Slot:
         a.ev_tgram = self.ev_tgram
         a.ev_tg0 = self.ev_tg0
         a.release_delay = RELEASE_DELAY
+        if p.cert_stream is not None:
+            a.cert_stream, a.cert_mirror, a.ev_cert = p.cert_stream.cuda_stream, self.cert_mirror.data_ptr(), self.ev_cert
         a.go_budget = EARLY_BUDGET
 
 
@@ -133,6 +138,10 @@ class SelectorChainPlan:
         self.device, self.mode = s.device, mode
         self.kmax_cap = self.d_s - 1
         self.chain_stream, self.student_stream, self.tail_stream = streams
+        # the rank certificate (BasdSelectorChain.cert_mirror) is queued on the chain's own stream, between the teacher Grams
+        # and the factorisation (~10 us).  On a stream of its own it cost 0.4 ms per step (2.43 against 2.03-2.07 ms with the
+        # read-back deferred): one more stream among the step's six made launches of unrelated streams wait for each other
+        self.cert_stream = self.chain_stream if CERTIFICATE else None
         self.slots = [_Slot(self), _Slot(self)]
         self.turn = 0
         self.hint = 0                      # previous step's largest rank (0: none yet)
@@ -208,6 +217,15 @@ class SelectorChainPlan:
         _lib.call("basd_event_synchronize", slot.ev_ranks)
         host = slot.mirror.tolist()
         return host[:self.L], host[self.L:]
+
+    def ranks_certified(self, slot: _Slot) -> bool:
+        """Block on the certificate kernel of ``slot`` (queued behind the teacher Grams, ~0.6 ms into the chain): True when
+        it has PROVEN that no teacher layer of this step has Marchenko-Pastur rank 0 -- the reference's forward cannot
+        raise, and the read-back of the ranks themselves may be left to the next step."""
+        if self.cert_stream is None:
+            return False
+        _lib.call("basd_event_synchronize", slot.ev_cert)
+        return int(slot.cert_mirror[0]) == 1
 
     def finish_tail(self, slot: _Slot, ranks: list[int]) -> torch.Tensor:
         """Make sure the tail of ``slot`` has been queued with enough eigenvectors for ``ranks``; returns d_grass_sq

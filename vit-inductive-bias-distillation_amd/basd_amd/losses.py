@@ -1054,10 +1054,20 @@ class BASDLoss(nn.Module):
         )
         self.last_components: dict[str, torch.Tensor] = {}
         self._side_streams: dict = {}
-        # The reference reads the ranks (and raises on rank 0) inside forward; so do we.  BASD_RANK_READBACK=deferred
-        # (or ``sync_ranks = False``): with one teacher layer the ranks do not feed the loss, the read-back is then
-        # completed by the next forward / the first reader of ``subspace_ranks`` and consecutive steps may overlap.
-        self.sync_ranks = os.environ.get("BASD_RANK_READBACK", "sync") != "deferred"
+        # The reference reads the ranks (and raises on rank 0) inside forward; so do we -- but with one teacher layer the
+        # ranks do not feed the loss, and waiting for them is waiting for the whole factorisation (~1.5 ms).
+        #   "auto" (default): a small kernel behind the teacher Grams PROVES "no rank is 0" where the spectrum allows it
+        #       (BasdSelectorChain.cert_mirror: largest eigenvalue >= ||G||_F^2 / tr G against median <= tr G / (n/2), with a
+        #       factor 4 to spare); the host waits for that word (~0.65 ms into the step) and, when it is set, leaves the
+        #       read-back of the ranks to the next forward / the first reader of ``subspace_ranks`` -- forward cannot have
+        #       raised.  Not proven (a flat spectrum, NaNs, shapes the chain does not take): the read-back happens inside
+        #       forward as in the reference.
+        #   "sync": always inside forward.   "deferred" (``sync_ranks = False``): never -- a rank-0 layer then raises one
+        #       step late.
+        self.rank_readback = os.environ.get("BASD_RANK_READBACK", "auto")
+        if self.rank_readback not in ("auto", "sync", "deferred"):
+            raise ValueError(f"BASD_RANK_READBACK={self.rank_readback!r}: expected auto, sync or deferred")
+        self.readback_deferred_steps = 0       # steps whose read-back was left to the next call (diagnostics)
         # single-teacher steps: the selector as ONE library call into a persistent workspace (basd_selector_chain);
         # BASD_SELECTOR_CHAIN=0 keeps the kernel-by-kernel layout.  chain_mode: see BasdSelectorChain.mode
         self.use_chain = os.environ.get("BASD_SELECTOR_CHAIN", "1") != "0"
@@ -1065,6 +1075,7 @@ class BASDLoss(nn.Module):
         # which of the step's two chains the host queues first: the Procrustes kernels of the caller's stream or the selector
         self.procrustes_first = os.environ.get("BASD_PROCRUSTES_FIRST", "0") == "1"
         self.student_low_priority = os.environ.get("BASD_STUDENT_LOW_PRIORITY", "1") == "1"
+        self.tail_low_priority = os.environ.get("BASD_TAIL_LOW_PRIORITY", "0") != "0"
         self._chain_plans: dict = {}
 
     def _selector_stream(self, device, index: int = 0) -> "torch.cuda.Stream":
@@ -1076,6 +1087,15 @@ class BASDLoss(nn.Module):
             prio = -1 if (mode == "1" and index % 3 < 2) or (mode == "2" and index % 3 == 0) else 0
             self._side_streams[key] = torch.cuda.Stream(device=device, priority=prio)
         return self._side_streams[key]
+
+    @property
+    def sync_ranks(self) -> bool:
+        """True unless the rank read-back is ALWAYS left to the next call (``rank_readback == "deferred"``)."""
+        return self.rank_readback != "deferred"
+
+    @sync_ranks.setter
+    def sync_ranks(self, value: bool) -> None:
+        self.rank_readback = "sync" if value else "deferred"
 
     def _forward_single_teacher_legacy(self, student_output, targets, students, keys, teachers, attns, comp):
         """One teacher layer, shapes ``basd_selector_chain`` does not take (fewer teacher tokens than student features:
@@ -1196,6 +1216,16 @@ class BASDLoss(nn.Module):
                         ops._lib.call("basd_stream_create_priority", ctypes.byref(h), 1)
                     self._side_streams[key_s] = torch.cuda.ExternalStream(h.value, device=main.device)
                 streams[1] = self._side_streams[key_s]
+            if self.tail_low_priority:
+                # ... and so is the selector's tail (its d_grass_sq is only published)
+                key_t = (str(main.device), "tail-low")
+                if key_t not in self._side_streams:
+                    import ctypes
+                    h = ctypes.c_void_p()
+                    with torch.cuda.device(main.device):
+                        ops._lib.call("basd_stream_create_priority", ctypes.byref(h), 1)
+                    self._side_streams[key_t] = torch.cuda.ExternalStream(h.value, device=main.device)
+                streams[2] = self._side_streams[key_t]
             streams = tuple(streams)
             plan = self._chain_plans[key] = SelectorChainPlan(students, teachers, self.chain_mode, streams,
                                                               fact_stream=self._selector_stream(main.device, 3))
@@ -1268,11 +1298,14 @@ class BASDLoss(nn.Module):
             # (written on the selector's tail stream: synchronise the device before reading it)
             comp["d_grass_sq"] = plan.finish_tail(slot, ranks)
 
-        if self.sync_ranks:
+        defer = self.rank_readback == "deferred" or (self.rank_readback == "auto" and plan.ranks_certified(slot))
+        ops.trace("ranks_certified")
+        if not defer:
             if previous is not None:
                 previous()
             complete()
         else:
+            self.readback_deferred_steps += 1
             # deferred: this step's ranks are read by the next forward or by the first reader of ``subspace_ranks``;
             # the PREVIOUS step's now, with this step already queued (its rank kernel finished long ago -- if not,
             # this wait is the back-pressure that keeps the host at most one step ahead)

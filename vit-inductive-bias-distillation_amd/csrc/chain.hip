@@ -35,6 +35,61 @@ __global__ void chain_k_arr_kernel(const int* __restrict__ ranks, int L, int ite
     }
 }
 
+// Rank certificate (BasdSelectorChain.cert_mirror, basd_rank_certificate): flag = 1 iff for every one of the L symmetric
+// n x n matrices G (uncentred teacher Grams / M = A + zbar zbar^T, A = the centred Gram / M, PSD)
+//     max(|zbar|^2, ||G||_F^2 / tr G)  >  1.5 factor min(tr G / c, (tr G - |zbar|^2) / (c - 1)),    c = n - (n - 1) / 2.
+// Left: lower bounds of the largest eigenvalue (Rayleigh quotient of zbar; sum l^2 <= l_1 sum l).  Right: upper bounds of
+// the lower median l_c -- c eigenvalues are >= it and all are >= 0, so c l_c <= tr G; and l_c(G) <= l_{c-1}(A) (rank-one
+// interlacing) <= tr A / (c - 1).  The 1.5 covers what fp32 does to the computed spectrum (errors ~ n eps l_1 = 2e-5 l_1: 1.001 would do).  Then l_1 > fp32(l_c
+// factor): no Marchenko-Pastur rank is 0.  One workgroup; sums in fp64.
+__global__ void __launch_bounds__(1024) rank_certificate_kernel(const float* __restrict__ grams, const float* __restrict__ zbar,
+                                                                int n, int L, double factor, int* __restrict__ host_flag) {
+    __shared__ double part[3][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long nn = (long)n * n;
+    int ok = 1;
+    for (int l = 0; l < L; ++l) {
+        const float* g = grams + l * nn;
+        double s2 = 0.0, tr = 0.0, zz = 0.0;
+        for (long idx = tid; idx < nn; idx += 1024) {
+            const double v = (double)g[idx];
+            s2 = fma(v, v, s2);
+        }
+        for (int i = tid; i < n; i += 1024) {
+            tr += (double)g[(long)i * n + i];
+            if (zbar) {
+                const double z = (double)zbar[(long)l * n + i];
+                zz = fma(z, z, zz);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            s2 += __shfl_down(s2, off, 64);
+            tr += __shfl_down(tr, off, 64);
+            zz += __shfl_down(zz, off, 64);
+        }
+        __syncthreads();
+        if (lane == 0) { part[0][wave] = s2; part[1][wave] = tr; part[2][wave] = zz; }
+        __syncthreads();
+        if (tid == 0) {
+            double a = 0.0, b = 0.0, z = 0.0;
+            for (int w = 0; w < 16; ++w) { a += part[0][w]; b += part[1][w]; z += part[2][w]; }
+            const double c = (double)(n - (n - 1) / 2);
+            bool good = false;
+            if (b > 0.0 && c > 1.0) {
+                const double lo = fmax(z, a / b);
+                const double tr_a = fmax(b - z, 1e-4 * b);      // the subtraction cancels when the mean dominates: floor it
+                const double hi = fmin(b / c, tr_a / (c - 1.0));
+                good = lo > 1.5 * factor * hi;
+            }
+            if (!good) ok = 0;       // also catches NaN
+        }
+    }
+    if (tid == 0) {
+        *host_flag = ok;
+        __threadfence_system();
+    }
+}
+
 // A fixed delay (no memory polling: it cannot deadlock, whatever runs or does not run beside it): one wave asleep for
 // ~3.4 us x `rounds` at 2.4 GHz.  Queued at the head of the student side (mode 3), which the teacher's Grams release: the whole-CU factorisation workgroups of the teacher side, released by the same Grams on
 // another stream, get their CUs BEFORE the student side's throughput launches refill every free slot.
@@ -150,6 +205,13 @@ int basd_selector_chain_tail(const BasdSelectorChain* a, int kmax, int exact_k) 
     return BASD_OK;
 }
 
+int basd_rank_certificate(const float* grams, const float* zbar, int n, int batch, double factor, int* flag,
+                          hipStream_t stream) {
+    BASD_CHECK_ARG(grams && flag && n > 2 && batch > 0 && factor > 0.0);
+    basd::rank_certificate_kernel<<<1, 1024, 0, stream>>>(grams, zbar, n, batch, factor, flag);
+    BASD_RETURN_LAST();
+}
+
 int basd_selector_chain(const BasdSelectorChain* a) {
     BASD_CHECK_ARG(a && a->teacher_host_ptrs && a->student_ptrs && a->proj_t && a->z && a->z_sums && a->z_ptrs &&
                    a->z_means && a->t_slabs && a->s_partial && a->s_means && a->s_slabs && a->grams && a->d && a->e &&
@@ -199,9 +261,15 @@ int basd_selector_chain(const BasdSelectorChain* a) {
                              (int)a->t_splits, a->t_slabs, a->grams + (long)L * nn, nn, 1, nullptr, 0, 0, cs));
     BASD_TRY(basd_gram_finish(a->grams + (long)L * nn, a->z_means, n, L, M_t, a->grams, nullptr, cs));
     BASD_MARK(a->tm_tgram, cs);
-    if (mode == 3) {
-        BASD_CHECK_ARG(a->ev_tg0 != nullptr);
-        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_tg0, cs));
+    if (mode == 3) BASD_CHECK_ARG(a->ev_tg0 != nullptr);
+    if (a->ev_tg0) BASD_HIP(hipEventRecord((hipEvent_t)a->ev_tg0, cs));
+    if (a->cert_mirror) {
+        // "every rank >= 1", proven from the uncentred Grams alone where the spectrum allows it (see the header): the host
+        // then need not wait for the factorisation to know that the reference would not have raised
+        BASD_CHECK_ARG(a->cert_stream && a->ev_cert && a->ev_tg0);
+        if (a->cert_stream != cs) BASD_HIP(hipStreamWaitEvent(a->cert_stream, (hipEvent_t)a->ev_tg0, 0));
+        BASD_TRY(basd_rank_certificate(a->grams, a->z_means, n, L, a->mp_factor, a->cert_mirror, a->cert_stream));
+        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_cert, a->cert_stream));
     }
 
     auto student_grams = [&](hipStream_t st) -> int {
