@@ -322,7 +322,7 @@ typedef struct BasdSelectorChain {
      * student column means, tm_sgram = behind the student Grams, tm_tri0 = in front of the factorisation (ev_ranks ends
      * it), tm_mid = between its two stages, tm_spec = behind the spectra at the head of the tail */
     void* tm_proj; void* tm_tgram; void* tm_scol0; void* tm_scol1; void* tm_sgram; void* tm_tri0; void* tm_mid; void* tm_spec;
-    /* Rank certificate (all three nullable together).  The reference raises inside forward when a teacher layer has MP
+    /* Rank certificate (all four nullable together).  The reference raises inside forward when a teacher layer has MP
      * rank 0 (layer_selector.py:16-19 -> NaN weights -> torch.linalg.svd raises), which is what the host waits ~1.5 ms
      * for.  Behind the teacher Grams -- long before the factorisation -- one small kernel on cert_stream proves
      * "every rank >= 1" where it can: with eigenvalues l_1 >= ... >= l_n >= 0 of the uncentred Gram G = A + zbar zbar^T,
@@ -332,14 +332,18 @@ typedef struct BasdSelectorChain {
      * layers, else 0 (flat spectra, NaN: the caller then waits for the ranks as before); ev_cert is recorded behind it.
      * cert_stream may be chain_stream (the kernel then sits between the Grams and the factorisation; measured best). */
     hipStream_t cert_stream; int* cert_mirror; void* ev_cert;
+    double* cert_scratch;                  /* basd_rank_certificate_scratch_bytes(L) bytes, ZEROED once (the kernel leaves it zeroed) */
 } BasdSelectorChain;
 int basd_selector_chain(const BasdSelectorChain* args);
 /* The certificate kernel of BasdSelectorChain.cert_mirror on its own: *flag (device or pinned host memory) = 1 iff
  *     max(|zbar|^2, ||G||_F^2 / tr G) > 1.5 factor min(tr G / c, (tr G - |zbar|^2) / (c - 1)),   c = n - (n-1)/2,
  * holds for every one of the `batch` symmetric n x n matrices G = A + zbar zbar^T (A PSD; zbar (batch, n) nullable = 0)
  * -- a sufficient condition for "every Marchenko-Pastur rank (layer_selector.py:16-19) is >= 1"; else 0. */
-int basd_rank_certificate(const float* grams, const float* zbar, int n, int batch, double factor, int* flag,
-                          hipStream_t stream);
+int basd_rank_certificate(const float* grams, const float* zbar, int n, int batch, double factor, double* scratch,
+                          int* flag, hipStream_t stream);
+/* scratch: basd_rank_certificate_scratch_bytes(batch) bytes of device memory, zeroed before the FIRST launch that uses
+ * it (partial sums + a ticket; the launch leaves it zeroed again). */
+long basd_rank_certificate_scratch_bytes(int batch);
 /* exact_k != 0: the caller has READ the ranks and every one of them equals kmax (one teacher layer): the principal-angle
  * matrices then have one common order and may leave LDS (orders past basd_jacobi_lds_square_fits; a speculative kmax
  * past it returns BASD_EUNSUPPORTED). */

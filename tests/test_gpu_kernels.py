@@ -491,10 +491,11 @@ def test_rank_certificate_is_sound(dev):
         "zero": torch.zeros(n, dtype=torch.float64),
     }
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = torch.zeros(_lib.query("basd_rank_certificate_scratch_bytes", 2), dtype=torch.uint8, device=dev)
     fired = {}
     for name, ev in spectra.items():
         G = gram(ev).to(dev).contiguous()
-        _lib.call("basd_rank_certificate", G.data_ptr(), None, n, 1, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.call("basd_rank_certificate", G.data_ptr(), None, n, 1, factor, scratch.data_ptr(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
         fired[name] = int(flag.item())
         if fired[name]:
             assert mp_rank(G.cpu()) >= 1, name
@@ -507,7 +508,7 @@ def test_rank_certificate_is_sound(dev):
         ev = torch.rand(n, generator=g, dtype=torch.float64) + 0.5
         ev[:k] *= 10.0 ** float(torch.rand(1, generator=g) * 2)
         G = gram(ev).to(dev).contiguous()
-        _lib.call("basd_rank_certificate", G.data_ptr(), None, n, 1, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.call("basd_rank_certificate", G.data_ptr(), None, n, 1, factor, scratch.data_ptr(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
         if int(flag.item()):
             assert mp_rank(G.cpu()) >= 1, (trial, k)
     # a flat spectrum plus a large mean: only the mean-based bounds can see that (uncentred Grams of features with a mean)
@@ -517,20 +518,21 @@ def test_rank_certificate_is_sound(dev):
         z = (zb * scale).float()
         G = (gram(torch.ones(n, dtype=torch.float64)).double() + torch.outer(z.double(), z.double())).float().to(dev).contiguous()
         zd = z.to(dev).contiguous()
-        _lib.call("basd_rank_certificate", G.data_ptr(), zd.data_ptr(), n, 1, factor, flag.data_ptr(),
+        _lib.call("basd_rank_certificate", G.data_ptr(), zd.data_ptr(), n, 1, factor, scratch.data_ptr(), flag.data_ptr(),
                   torch.cuda.current_stream().cuda_stream)
         assert int(flag.item()) == expect
         if expect:
             assert mp_rank(G.cpu()) >= 1
     # a batch is certified only if EVERY matrix is; NaN never certifies
     both = torch.stack([gram(spectra["signal_12"]), gram(spectra["flat"])]).to(dev).contiguous()
-    _lib.call("basd_rank_certificate", both.data_ptr(), None, n, 2, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.call("basd_rank_certificate", both.data_ptr(), None, n, 2, factor, scratch.data_ptr(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert int(flag.item()) == 0
     both[1] = both[0]
-    _lib.call("basd_rank_certificate", both.data_ptr(), None, n, 2, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.call("basd_rank_certificate", both.data_ptr(), None, n, 2, factor, scratch.data_ptr(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert int(flag.item()) == 1
+    assert not scratch.any(), "every launch leaves its scratch zeroed"
     both[1, 3, 5] = float("nan")
-    _lib.call("basd_rank_certificate", both.data_ptr(), None, n, 2, factor, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.call("basd_rank_certificate", both.data_ptr(), None, n, 2, factor, scratch.data_ptr(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert int(flag.item()) == 0
 
 

@@ -95,7 +95,8 @@ SIGNATURES = {
     "basd_grassmann_distance_bwd": [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, vp],
     "basd_eigvec_k2": [vp, vp, i32, i32, i32, vp, vp],
     "basd_selector_chain": [vp],
-    "basd_rank_certificate": [vp, vp, i32, i32, f64, vp, vp],
+    "basd_rank_certificate": [vp, vp, i32, i32, f64, vp, vp, vp],
+    "basd_rank_certificate_scratch_bytes": [i32],
     "basd_selector_chain_tail": [vp, i32, i32],
     "basd_jacobi_lds_square_fits": [i32],
     "basd_event_record": [vp, vp],
@@ -143,7 +144,7 @@ class SelectorChainArgs(C.Structure):
                              "ev_fork", "ev_student", "ev_ranks", "ev_tail", "ev_slot_free", "ev_tgram", "ev_tg0",
                              "release_delay", "fact_stream", "go_flag", "go_value", "go_budget",
                              "tm_proj", "tm_tgram", "tm_scol0", "tm_scol1", "tm_sgram", "tm_tri0", "tm_mid", "tm_spec",
-                             "cert_stream", "cert_mirror", "ev_cert")]
+                             "cert_stream", "cert_mirror", "ev_cert", "cert_scratch")]
     )
 
 
@@ -151,7 +152,8 @@ EINVAL, EUNSUPPORTED = -1, -2        # BASD_EINVAL / BASD_EUNSUPPORTED of includ
 
 # sizing helpers declared `long` in include/basd_hip.h
 LONG_RESULTS = {"basd_tridiag_workspace_bytes", "basd_jacobi_twopass_workspace_bytes",
-                "basd_mix_grad_tokens_scratch_floats", "basd_teacher_center_stream_scratch_floats"}
+                "basd_mix_grad_tokens_scratch_floats", "basd_teacher_center_stream_scratch_floats",
+                "basd_rank_certificate_scratch_bytes"}
 
 _lock = threading.Lock()
 _lib = None

@@ -106,7 +106,10 @@ class _Slot:
         a.ev_tg0 = self.ev_tg0
         a.release_delay = RELEASE_DELAY
         if p.cert_stream is not None:
+            b["cert_scratch"] = torch.zeros((_lib.query("basd_rank_certificate_scratch_bytes", L),), device=dev,
+                                            dtype=torch.uint8)
             a.cert_stream, a.cert_mirror, a.ev_cert = p.cert_stream.cuda_stream, self.cert_mirror.data_ptr(), self.ev_cert
+            a.cert_scratch = b["cert_scratch"].data_ptr()
         a.go_budget = EARLY_BUDGET
 
 

@@ -40,52 +40,76 @@ __global__ void chain_k_arr_kernel(const int* __restrict__ ranks, int L, int ite
 //     max(|zbar|^2, ||G||_F^2 / tr G)  >  1.5 factor min(tr G / c, (tr G - |zbar|^2) / (c - 1)),    c = n - (n - 1) / 2.
 // Left: lower bounds of the largest eigenvalue (Rayleigh quotient of zbar; sum l^2 <= l_1 sum l).  Right: upper bounds of
 // the lower median l_c -- c eigenvalues are >= it and all are >= 0, so c l_c <= tr G; and l_c(G) <= l_{c-1}(A) (rank-one
-// interlacing) <= tr A / (c - 1).  The 1.5 covers what fp32 does to the computed spectrum (errors ~ n eps l_1 = 2e-5 l_1: 1.001 would do).  Then l_1 > fp32(l_c
-// factor): no Marchenko-Pastur rank is 0.  One workgroup; sums in fp64.
-__global__ void __launch_bounds__(1024) rank_certificate_kernel(const float* __restrict__ grams, const float* __restrict__ zbar,
-                                                                int n, int L, double factor, int* __restrict__ host_flag) {
-    __shared__ double part[3][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// interlacing) <= tr A / (c - 1).  The 1.5 covers what fp32 does to the computed spectrum (errors ~ n eps l_1 = 2e-5 l_1:
+// 1.001 would do).  Then l_1 > fp32(l_c factor): no Marchenko-Pastur rank is 0.  Sums in fp64.
+// Grid (CERT_BLOCKS, L) x 256 threads: partial sums go to `scratch` (4 doubles per matrix: ||G||_F^2, tr G, spare, spare;
+// then one int ticket) by fp64 atomics; the block that draws the last ticket evaluates the condition for every matrix,
+// writes the flag and leaves the scratch zeroed for the next launch.  Small workgroups on purpose: a 1024-thread block
+// waited ~80 us for a CU with 16 free wave slots inside a saturated step.
+constexpr int CERT_BLOCKS = 32;
+__global__ void __launch_bounds__(256) rank_certificate_kernel(const float* __restrict__ grams, const float* __restrict__ zbar,
+                                                               int n, int L, double factor, double* __restrict__ scratch,
+                                                               int* __restrict__ host_flag) {
+    __shared__ double part[2][4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = blockIdx.y;
     const long nn = (long)n * n;
-    int ok = 1;
-    for (int l = 0; l < L; ++l) {
-        const float* g = grams + l * nn;
-        double s2 = 0.0, tr = 0.0, zz = 0.0;
-        for (long idx = tid; idx < nn; idx += 1024) {
-            const double v = (double)g[idx];
-            s2 = fma(v, v, s2);
-        }
-        for (int i = tid; i < n; i += 1024) {
-            tr += (double)g[(long)i * n + i];
-            if (zbar) {
-                const double z = (double)zbar[(long)l * n + i];
+    const float* g = grams + l * nn;
+    double s2 = 0.0, tr = 0.0;
+    for (long idx = (long)blockIdx.x * 256 + tid; idx < nn; idx += (long)CERT_BLOCKS * 256) {
+        const double v = (double)g[idx];
+        s2 = fma(v, v, s2);
+    }
+    if (blockIdx.x == 0)
+        for (int i = tid; i < n; i += 256) tr += (double)g[(long)i * n + i];
+    for (int off = 32; off > 0; off >>= 1) {
+        s2 += __shfl_down(s2, off, 64);
+        tr += __shfl_down(tr, off, 64);
+    }
+    if (lane == 0) { part[0][wave] = s2; part[1][wave] = tr; }
+    __syncthreads();
+    int* ticket = (int*)(scratch + 4L * L);
+    if (tid == 0) {
+        atomicAdd(scratch + 4 * l + 0, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
+        if (blockIdx.x == 0) atomicAdd(scratch + 4 * l + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1) == CERT_BLOCKS * L - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // the last block: one wave per matrix in turn (|zbar|^2, then the test)
+    __shared__ int s_ok;
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    for (int m = wave; m < L; m += 4) {
+        double zz = 0.0;
+        if (zbar)
+            for (int i = lane; i < n; i += 64) {
+                const double z = (double)zbar[(long)m * n + i];
                 zz = fma(z, z, zz);
             }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            s2 += __shfl_down(s2, off, 64);
-            tr += __shfl_down(tr, off, 64);
-            zz += __shfl_down(zz, off, 64);
-        }
-        __syncthreads();
-        if (lane == 0) { part[0][wave] = s2; part[1][wave] = tr; part[2][wave] = zz; }
-        __syncthreads();
-        if (tid == 0) {
-            double a = 0.0, b = 0.0, z = 0.0;
-            for (int w = 0; w < 16; ++w) { a += part[0][w]; b += part[1][w]; z += part[2][w]; }
+        for (int off = 32; off > 0; off >>= 1) zz += __shfl_down(zz, off, 64);
+        if (lane == 0) {
+            const double a = __hip_atomic_load(scratch + 4 * m + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double b = __hip_atomic_load(scratch + 4 * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double c = (double)(n - (n - 1) / 2);
             bool good = false;
             if (b > 0.0 && c > 1.0) {
-                const double lo = fmax(z, a / b);
-                const double tr_a = fmax(b - z, 1e-4 * b);      // the subtraction cancels when the mean dominates: floor it
+                const double lo = fmax(zz, a / b);
+                const double tr_a = fmax(b - zz, 1e-4 * b);      // the subtraction cancels when the mean dominates: floor it
                 const double hi = fmin(b / c, tr_a / (c - 1.0));
                 good = lo > 1.5 * factor * hi;
             }
-            if (!good) ok = 0;       // also catches NaN
+            if (!good) atomicAnd(&s_ok, 0);       // also catches NaN
+            scratch[4 * m + 0] = 0.0;
+            scratch[4 * m + 1] = 0.0;
         }
     }
+    __syncthreads();
     if (tid == 0) {
-        *host_flag = ok;
+        *ticket = 0;
+        *host_flag = s_ok;
         __threadfence_system();
     }
 }
@@ -205,10 +229,13 @@ int basd_selector_chain_tail(const BasdSelectorChain* a, int kmax, int exact_k) 
     return BASD_OK;
 }
 
-int basd_rank_certificate(const float* grams, const float* zbar, int n, int batch, double factor, int* flag,
-                          hipStream_t stream) {
-    BASD_CHECK_ARG(grams && flag && n > 2 && batch > 0 && factor > 0.0);
-    basd::rank_certificate_kernel<<<1, 1024, 0, stream>>>(grams, zbar, n, batch, factor, flag);
+long basd_rank_certificate_scratch_bytes(int batch) { return batch > 0 ? 32L * batch + 8 : 0; }
+
+int basd_rank_certificate(const float* grams, const float* zbar, int n, int batch, double factor, double* scratch,
+                          int* flag, hipStream_t stream) {
+    BASD_CHECK_ARG(grams && flag && scratch && n > 2 && batch > 0 && batch <= 65535 && factor > 0.0);
+    basd::rank_certificate_kernel<<<dim3(basd::CERT_BLOCKS, batch), 256, 0, stream>>>(grams, zbar, n, batch, factor, scratch,
+                                                                                     flag);
     BASD_RETURN_LAST();
 }
 
@@ -266,9 +293,9 @@ int basd_selector_chain(const BasdSelectorChain* a) {
     if (a->cert_mirror) {
         // "every rank >= 1", proven from the uncentred Grams alone where the spectrum allows it (see the header): the host
         // then need not wait for the factorisation to know that the reference would not have raised
-        BASD_CHECK_ARG(a->cert_stream && a->ev_cert && a->ev_tg0);
+        BASD_CHECK_ARG(a->cert_stream && a->ev_cert && a->ev_tg0 && a->cert_scratch);
         if (a->cert_stream != cs) BASD_HIP(hipStreamWaitEvent(a->cert_stream, (hipEvent_t)a->ev_tg0, 0));
-        BASD_TRY(basd_rank_certificate(a->grams, a->z_means, n, L, a->mp_factor, a->cert_mirror, a->cert_stream));
+        BASD_TRY(basd_rank_certificate(a->grams, a->z_means, n, L, a->mp_factor, a->cert_scratch, a->cert_mirror, a->cert_stream));
         BASD_HIP(hipEventRecord((hipEvent_t)a->ev_cert, a->cert_stream));
     }
 
