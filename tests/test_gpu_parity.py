@@ -333,6 +333,7 @@ def test_early_launched_factorisation_gives_up_cleanly(golden, monkeypatch):
     # with its normal budget the early-launched factorisation delivers the same ranks / distances
     shape = synth.CONFIGS["cfg2"]
     mod = _module(shape, 0.001)
+    mod.chain_mode = 3                # the early launch belongs to the layout with the teacher matrices first
     inp = synth.make_inputs(shape, 1234, batch=8, device=DEV, strided=True)
     for _ in range(3):
         loss = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
@@ -342,6 +343,7 @@ def test_early_launched_factorisation_gives_up_cleanly(golden, monkeypatch):
     monkeypatch.setattr(chain, "EARLY_BUDGET", 1)
     shape = synth.CONFIGS["cfg2"]
     mod = _module(shape, 0.001)
+    mod.chain_mode = 3
     inp = synth.make_inputs(shape, 1234, batch=8, device=DEV, strided=True)
     with pytest.warns(RuntimeWarning, match="early-launched factorisation"):
         loss = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
@@ -352,6 +354,23 @@ def test_early_launched_factorisation_gives_up_cleanly(golden, monkeypatch):
     assert plan.early is False
     loss2 = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)          # no warning any more
     np.testing.assert_allclose(loss2.item(), g["cfg2_s1234_b8_loss"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_selector_chain_layouts_agree_with_the_reference(golden, mode):
+    """``basd_selector_chain`` in each of its four layouts (where the student side sits; one factorisation launch or two):
+    the reference's ranks, loss and d_grass_sq, step after step (two slots, speculative tail)."""
+    g = golden("baseline_scalars.npz")
+    shape = synth.CONFIGS["cfg2"]
+    mod = _module(shape, 0.001)
+    mod.chain_mode = mode
+    inp = synth.make_inputs(shape, 1234, batch=8, device=DEV, strided=True)
+    for _ in range(3):
+        loss = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
+        assert list(mod.layer_selector.subspace_ranks.values()) == list(g["cfg2_s1234_b8_ranks"])
+        np.testing.assert_allclose(loss.item(), g["cfg2_s1234_b8_loss"], rtol=1e-4)
+        np.testing.assert_allclose(_d_grass_sq(mod), g["cfg2_s1234_b8_d_grass_sq"], rtol=2e-4)
+    assert list(mod._chain_plans.values())[0].mode == mode
 
 
 def test_principal_angle_distance_cfg2_full_batch_vs_oracle():

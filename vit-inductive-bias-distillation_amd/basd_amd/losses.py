@@ -1071,7 +1071,12 @@ class BASDLoss(nn.Module):
         # single-teacher steps: the selector as ONE library call into a persistent workspace (basd_selector_chain);
         # BASD_SELECTOR_CHAIN=0 keeps the kernel-by-kernel layout.  chain_mode: see BasdSelectorChain.mode
         self.use_chain = os.environ.get("BASD_SELECTOR_CHAIN", "1") != "0"
-        self.chain_mode = int(os.environ.get("BASD_CHAIN_MODE", "3"))
+        # (None = by situation: 0 -- ONE factorisation launch over teacher and student matrices, student Grams beside the
+        # teacher's projection -- while the host does not wait for the ranks (the step is then bound by the GPU's total work:
+        # 1.92-1.95 ms at cfg-2 against 2.02-2.06 in mode 3); 3 -- teacher matrices first, student side held back -- in steps
+        # that follow one whose ranks had to be waited for (2.38 against 2.46))
+        self._chain_mode_forced = int(os.environ["BASD_CHAIN_MODE"]) if "BASD_CHAIN_MODE" in os.environ else None
+        self._last_step_waited = False
         # which of the step's two chains the host queues first: the Procrustes kernels of the caller's stream or the selector
         self.procrustes_first = os.environ.get("BASD_PROCRUSTES_FIRST", "0") == "1"
         self.student_low_priority = os.environ.get("BASD_STUDENT_LOW_PRIORITY", "1") == "1"
@@ -1087,6 +1092,16 @@ class BASDLoss(nn.Module):
             prio = -1 if (mode == "1" and index % 3 < 2) or (mode == "2" and index % 3 == 0) else 0
             self._side_streams[key] = torch.cuda.Stream(device=device, priority=prio)
         return self._side_streams[key]
+
+    @property
+    def chain_mode(self) -> int:
+        if self._chain_mode_forced is not None:
+            return self._chain_mode_forced
+        return 3 if (self.rank_readback == "sync" or self._last_step_waited) else 0
+
+    @chain_mode.setter
+    def chain_mode(self, value: int | None) -> None:
+        self._chain_mode_forced = None if value is None else int(value)
 
     @property
     def sync_ranks(self) -> bool:
@@ -1300,6 +1315,7 @@ class BASDLoss(nn.Module):
 
         defer = self.rank_readback == "deferred" or (self.rank_readback == "auto" and plan.ranks_certified(slot))
         ops.trace("ranks_certified")
+        self._last_step_waited = not defer
         if not defer:
             if previous is not None:
                 previous()
