@@ -11,8 +11,9 @@
  *     (pass torch.cuda.current_stream().cuda_stream); scratch buffers are caller-provided;
  *   - return value: 0 = ok, <0 = invalid argument / unsupported shape (BASD_E*), >0 = hipError_t;
  *   - dtype codes: 0 = fp32, 1 = bf16 (inputs only; all arithmetic and outputs are fp32/fp64);
- *   - entry points are re-entrant and keep no global mutable state, with three process-wide test / tuning hooks as the
- *     only exceptions: basd_tridiag_tuning, basd_jacobi_tuning, basd_jacobi_ordering, basd_procrustes_tuning (none is called by the loss).
+ *   - entry points are re-entrant and keep no global mutable state, with a few process-wide test / tuning hooks as the
+ *     only exceptions: basd_tridiag_tuning, basd_jacobi_tuning, basd_jacobi_ordering, basd_gemm_tuning, basd_procrustes_tuning (none is called by the
+ *     loss).
  */
 #ifndef BASD_HIP_H
 #define BASD_HIP_H
@@ -68,6 +69,11 @@ int basd_colmean_parts(int rows);
  * `partial`: batch*parts*cols floats of scratch. */
 int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_per_batch, long batch_stride,
                  int rows, int cols, int batch, int parts, float* partial, float* mean, hipStream_t stream);
+
+/* Test / tuning hook: 1 (default) = the Gram launches (basd_syrk_multi) run on the bf16 matrix cores with every staged fp32
+ * value cut into three bf16 pieces (exact) and the six leading piece products accumulated in fp32 -- fp32-grade results at
+ * 2.7x the fp32 MFMA ceiling; 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+int basd_gemm_tuning(int split_bf16);
 
 /* means[z][c] for a DEVICE table of n_mats same-layout matrices (one launch for all extraction layers of
  * layer_selector.py:88-91).  `partial`: n_mats*parts*cols floats of scratch.  vec_ok: caller asserts every base
@@ -344,6 +350,8 @@ int basd_rank_certificate(const float* grams, const float* zbar, int n, int batc
 /* scratch: basd_rank_certificate_scratch_bytes(batch) bytes of device memory, zeroed before the FIRST launch that uses
  * it (partial sums + a ticket; the launch leaves it zeroed again). */
 long basd_rank_certificate_scratch_bytes(int batch);
+/* Test hook: fills every CU's LDS with `pattern` (a NaN, say): no kernel may depend on what its CU's previous tenant left. */
+int basd_debug_fill_lds(unsigned pattern, hipStream_t stream);
 /* exact_k != 0: the caller has READ the ranks and every one of them equals kmax (one teacher layer): the principal-angle
  * matrices then have one common order and may leave LDS (orders past basd_jacobi_lds_square_fits; a speculative kmax
  * past it returns BASD_EUNSUPPORTED). */

@@ -343,21 +343,22 @@ def test_tridiag_lagging_member(dev, tuning, lag):
         assert torch.equal(getattr(ts, name), getattr(ref, name)), name
 
 
-@pytest.mark.parametrize("tail", [3, 1])
-def test_tridiag_members_under_uneven_load(dev, tuning, tail):
+@pytest.mark.parametrize("tail,n", [(3, 384), (1, 384), (1, 768)])
+def test_tridiag_members_under_uneven_load(dev, tuning, tail, n):
     """Hand-off stress: two shared-matrix factorisations on two streams while a third stream keeps the chip busy
     with long MFMA workgroups (the situation of a training step).  Every launch must reproduce the idle-chip
     result bit for bit and leave its status word at zero.  tail=3: the shared stage (members polling each other);
-    tail=1: the packed kernel (nothing to hand off: must be bit-stable under load all the same)."""
+    tail=1: the packed kernel at 384 (nothing to hand off: must be bit-stable under load all the same), the shared stage
+    as production runs it at 768.  (Round 3: this test caught member workgroups of fewer than 1024 threads going wrong
+    beside the split-operand Gram launch -- see tridiag_impl.)"""
     from basd_amd import ops
     tuning(tail=tail)
     g = torch.Generator().manual_seed(11)
-    n = 384
     xa = torch.randn(2, 4 * n, n, generator=g)
     xb = torch.randn(4, 4 * n, n, generator=g)
     Ga, Gb = (xa.transpose(1, 2) @ xa).to(dev), (xb.transpose(1, 2) @ xb).to(dev)
     ra, rb = ops.tridiag_eigenvalues(Ga.clone()), ops.tridiag_eigenvalues(Gb.clone())    # idle chip
-    big = [torch.randn(256, 197, n, generator=g).to(dev)[:, 1:, :] for _ in range(4)]
+    big = [torch.randn(256 * 384 // n, 197, n, generator=g).to(dev)[:, 1:, :] for _ in range(4)]
     s1, s2, s3 = (torch.cuda.Stream() for _ in range(3))
     torch.cuda.synchronize()
     for it in range(25):
@@ -372,6 +373,29 @@ def test_tridiag_members_under_uneven_load(dev, tuning, tail):
         for got, ref in ((ta, ra), (tb, rb)):
             for name in ("d", "e", "tau", "vh"):
                 assert torch.equal(getattr(got, name), getattr(ref, name)), (it, name)
+
+
+@pytest.mark.parametrize("tail", [3, 1])
+@pytest.mark.parametrize("n", [384, 768, 200])
+def test_tridiag_does_not_read_stale_lds(dev, tuning, tail, n):
+    """Whatever the previous tenant of a CU left in LDS (zeros, NaNs, another kernel's tiles) must not reach the
+    factorisation: bit-identical d, e, tau, reflectors and spectra behind ``basd_debug_fill_lds`` with two patterns."""
+    from basd_amd import ops, _lib
+    tuning(tail=tail)
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(3, 4 * n, n, generator=g)
+    G = (x.transpose(1, 2) @ x).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    out = []
+    for pattern in (0x00000000, 0x7FC00000, 0x3F800000):
+        _lib.call("basd_debug_fill_lds", pattern, st)
+        ts = ops.tridiag_eigenvalues(G.clone())
+        torch.cuda.synchronize()
+        assert int(ts.err[0].item()) == 0
+        out.append(ts)
+    for other in out[1:]:
+        for name in ("d", "e", "tau", "vh", "vals"):
+            assert torch.equal(getattr(out[0], name), getattr(other, name)), name
 
 
 @pytest.mark.parametrize("n,k", [(384, 48), (192, 20), (768, 80), (100, 100), (45, 10)])

@@ -31,6 +31,7 @@ SIGNATURES = {
     "basd_jacobi_stacked_twopass": [vp, i64, i32, i32, vp, i32, i32, f32, vp, vp, vp],
     "basd_jacobi_tuning": [i32],
     "basd_jacobi_ordering": [i32],
+    "basd_gemm_tuning": [i32],
     "basd_jacobi_onesided": [vp, i64, i32, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp],
     "basd_sort_extract": [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
     "basd_tridiag_workspace_bytes": [i32, i32],
@@ -97,6 +98,7 @@ SIGNATURES = {
     "basd_selector_chain": [vp],
     "basd_rank_certificate": [vp, vp, i32, i32, f64, vp, vp, vp],
     "basd_rank_certificate_scratch_bytes": [i32],
+    "basd_debug_fill_lds": [C.c_uint, vp],
     "basd_selector_chain_tail": [vp, i32, i32],
     "basd_jacobi_lds_square_fits": [i32],
     "basd_event_record": [vp, vp],

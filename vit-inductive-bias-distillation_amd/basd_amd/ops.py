@@ -24,6 +24,8 @@ TWO_PASS_LOG_LIMIT = 16 << 30     # bytes of rotation log above which the block 
 # Symmetric eigen-solver for the selector's D_s x D_s Grams when only eigenvalues / leading eigenvectors are
 # needed: "tridiag" (Householder + bisection + inverse iteration) or "jacobi" (block one-sided Jacobi).
 EIG_SOLVER = os.environ.get("BASD_EIG_SOLVER", "tridiag")
+if os.environ.get("BASD_GEMM_SPLIT") in ("0", "1"):      # A/B hook: 0 = fp32 MFMA Gram launches (basd_gemm_tuning)
+    _lib.call("basd_gemm_tuning", int(os.environ["BASD_GEMM_SPLIT"]))
 if os.environ.get("BASD_JACOBI_ORDERING") in ("0", "1"):      # A/B hook: 0 = round-robin through LDS (basd_jacobi_ordering)
     _lib.call("basd_jacobi_ordering", int(os.environ["BASD_JACOBI_ORDERING"]))
 

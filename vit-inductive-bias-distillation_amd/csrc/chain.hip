@@ -114,6 +114,13 @@ __global__ void __launch_bounds__(256) rank_certificate_kernel(const float* __re
     }
 }
 
+__global__ void __launch_bounds__(256) debug_fill_lds_kernel(unsigned pattern, int words) {
+    extern __shared__ unsigned fill_words[];
+    for (int i = threadIdx.x; i < words; i += 256) fill_words[i] = pattern;
+    __syncthreads();
+    if (fill_words[(threadIdx.x * 97) % words] != pattern) __builtin_trap();      // keeps the stores
+}
+
 // A fixed delay (no memory polling: it cannot deadlock, whatever runs or does not run beside it): one wave asleep for
 // ~3.4 us x `rounds` at 2.4 GHz.  Queued at the head of the student side (mode 3), which the teacher's Grams release: the whole-CU factorisation workgroups of the teacher side, released by the same Grams on
 // another stream, get their CUs BEFORE the student side's throughput launches refill every free slot.
@@ -227,6 +234,15 @@ int basd_selector_chain_tail(const BasdSelectorChain* a, int kmax, int exact_k) 
     BASD_TRY(basd_grassmann_distance(a->sigma, kmax, a->k_arr, a->sw, kmax, a->sw_index, items, a->d_out, nullptr, st));
     BASD_HIP(hipEventRecord((hipEvent_t)a->ev_tail, st));
     return BASD_OK;
+}
+
+// Test hook: every CU's LDS filled with `pattern` (e.g. a NaN): kernels must not depend on what the previous tenant of
+// their CU left in LDS (tests/test_gpu_kernels.py runs the solvers behind it and demands bit-identical results).
+int basd_debug_fill_lds(unsigned pattern, hipStream_t stream) {
+    const int bytes = 80 * 1024;
+    (void)hipFuncSetAttribute((const void*)basd::debug_fill_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    basd::debug_fill_lds_kernel<<<4096, 256, bytes, stream>>>(pattern, bytes / 4);
+    BASD_RETURN_LAST();
 }
 
 long basd_rank_certificate_scratch_bytes(int batch) { return batch > 0 ? 32L * batch + 8 : 0; }

@@ -536,6 +536,174 @@ __global__ void __launch_bounds__(256) syrk_tn_kernel(const void* const* __restr
     store_tile(C, cols, cols, cols, m0, n0, acc, wm, wn, lane, 1.f);
 }
 
+// ---------------------------------------------------------------------------
+// The same Gram launch on the bf16 matrix cores, with fp32 results: "split" operands.
+//   fp32 MFMA runs at 157 TF dense on this chip, bf16 MFMA at 2.5 PF.  Every staged value (x - mean, fp32) is cut into
+//   three bf16 pieces hi + mid + lo = x EXACTLY (round-to-nearest pieces of 8 significant bits each: 24 in all), once,
+//   while the slab goes to LDS; a product x y is then the six piece products of order <= 2^-16 (hi hi, hi mid, mid hi,
+//   mid mid, hi lo, lo hi: each exact in fp32), accumulated in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  What is
+//   dropped (mid lo, lo mid, lo lo) is below 2^-24 |x y| with either sign -- less than the rounding of one fp32 product.
+//   6 bf16 MFMAs replace 8 fp32 ones per 16 contraction steps at 16x the rate each: 2.7x the fp32 MFMA ceiling.
+//   LDS image per operand: three planes [octet of k][column position][8 bf16] (24 KB per 32-row slab): one ds_read_b128
+//   IS the 8-element operand of a lane.  Column c = 4 l + e of the 128-column slab sits at position 32 e + l, so that the
+//   staging threads (4 consecutive columns each, float4 global loads) store conflict-free; the MFMA lane i of 32-block
+//   b therefore holds column 4 i + b, and the epilogue stores C with that map.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SPLIT_PLANE = (TN_BK / 8) * 128 * 8;       // bf16 elements of one plane of one operand slab
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// (a, b) -> packed bf16 pieces (hi, mid, lo) with a = hi_a + mid_a + lo_a exactly, likewise b
+__device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    mid = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
+    lo = cvt_pk_bf16(sa, sb);
+}
+
+__device__ __forceinline__ void tn_store_lds_split(unsigned short* __restrict__ tile, int t, const float (&reg)[2][4][4],
+                                                   const float (&m4)[4]) {
+    const int l = t & 31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int kg = (t >> 5) + 4 * j, o = kg >> 1, half = kg & 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(reg[j][0][e] - m4[e], reg[j][1][e] - m4[e], h0, m0, l0);
+            split3(reg[j][2][e] - m4[e], reg[j][3][e] - m4[e], h1, m1, l1);
+            unsigned short* p = tile + ((o * 128 + 32 * e + l) << 3) + 4 * half;
+            *(uint2*)(p) = make_uint2(h0, h1);
+            *(uint2*)(p + SPLIT_PLANE) = make_uint2(m0, m1);
+            *(uint2*)(p + 2 * SPLIT_PLANE) = make_uint2(l0, l1);
+        }
+    }
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) syrk_tn_split_kernel(const void* const* __restrict__ ptrs, GemmOperand X, int cols,
+                                                            int Krows, int splits, int n_mats, int pairs,
+                                                            const float* __restrict__ means, float* __restrict__ slabs,
+                                                            const float* __restrict__ fold, int fold_parts, int fold_from) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 3 * SPLIT_PLANE];
+    int pair, unit;       // XCD-aware decode: see syrk_tn_kernel
+    {
+        const int units = splits * n_mats, id = blockIdx.x;
+        if ((units & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3;
+            pair = slot % pairs;
+            unit = xcd + 8 * (slot / pairs);
+        } else {
+            pair = id % pairs;
+            unit = id / pairs;
+        }
+    }
+    int tmi, tni;
+    tri_tile(pair, tmi, tni);
+    const bool diag = tmi == tni;
+    unsigned short* tA = lds;
+    unsigned short* tB = diag ? lds : lds + 3 * SPLIT_PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = tmi * BM, n0 = tni * BN;
+    const int z = unit / splits, sp = unit - z * splits;
+    X.ptr = ptrs[z];
+    const float* mean = means ? means + (long)z * cols : nullptr;
+    float* C = slabs + ((long)z * splits + sp) * (long)cols * cols;
+    const int chunks = (Krows + TN_BK - 1) / TN_BK;
+    const int per = (chunks + splits - 1) / splits;
+    const int k_begin = sp * per * TN_BK;
+    int k_end = k_begin + per * TN_BK;
+    if (k_end > Krows) k_end = Krows;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool is_b = tid >= 128;
+    const bool loader = !(is_b && diag);       // wave-uniform
+    const int t = tid & 127;
+    const int col0 = is_b ? n0 : m0;
+    unsigned short* tile = is_b ? tB : tA;
+    float reg[2][4][4], m4[4];
+    TnCursor cu;
+    tn_cursor_init(cu, X, k_begin, t);
+    if (fold && z >= fold_from) {
+        const float* fp = fold + (long)(z - fold_from) * fold_parts * cols;
+        const int c = col0 + (t & 31) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = 0.f;
+            if (c + e < cols)
+                for (int p = 0; p < fold_parts; ++p) s += fp[(long)p * cols + c + e];
+            m4[e] = s * (1.f / Krows);
+        }
+    } else {
+        tn_mean4(mean, cols, col0, t, m4);
+    }
+    if (loader && k_begin < k_end) tn_load<T, VEC>(X, cu, k_end, cols, k_begin, col0, t, m4, reg);
+    const int i = lane & 31, h = lane >> 5;
+    for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
+        __syncthreads();
+        if (loader) tn_store_lds_split(tile, t, reg, m4);
+        __syncthreads();
+        if (loader && k0 + TN_BK < k_end) {
+            tn_cursor_advance(cu, X);
+            tn_load<T, VEC>(X, cu, k_end, cols, k0 + TN_BK, col0, t, m4, reg);
+        }
+#pragma unroll
+        for (int s16 = 0; s16 < TN_BK / 16; ++s16) {
+            bf16x8 a[2][3], b[2][3];
+            const int o = 2 * s16 + h;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[mi][p] = *(const bf16x8*)(tA + p * SPLIT_PLANE + ((o * 128 + (wm * 2 + mi) * 32 + i) << 3));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[ni][p] = *(const bf16x8*)(tB + p * SPLIT_PLANE + ((o * 128 + (wn * 2 + ni) * 32 + i) << 3));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    f32x16 c = acc[mi][ni];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
+                    acc[mi][ni] = c;
+                }
+        }
+    }
+    // epilogue: MFMA lane i of 32-block b holds slab column 4 i + b (rows of C from the A side, columns from the B side)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + 4 * i + (wn * 2 + ni);
+            if (col >= cols) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + (wm * 2 + mi);
+                if (row < cols) C[(long)row * cols + col] = acc[mi][ni][r];
+            }
+        }
+}
+
 // grid = (tile pairs * 64, n_mats), block 256: one element of a lower tile per thread.
 __global__ void __launch_bounds__(256) syrk_reduce_kernel(const float* __restrict__ slabs, int cols, int splits,
                                                           const float* __restrict__ scales, float* __restrict__ out,
@@ -547,7 +715,10 @@ __global__ void __launch_bounds__(256) syrk_reduce_kernel(const float* __restric
     if (r >= cols || c >= cols) return;
     const int z = blockIdx.y;
     const long mat = (long)cols * cols;
-    const float* in = slabs + (long)z * splits * mat + (long)r * cols + c;
+    // a diagonal tile holds both triangles; the upper one is taken from the lower (the split-operand kernel sums the
+    // piece products of (r, c) and (c, r) in different orders: equal to rounding, not bit for bit)
+    const bool up = tmi == tni && r < c;
+    const float* in = slabs + (long)z * splits * mat + (up ? (long)c * cols + r : (long)r * cols + c);
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += in[k * mat];
     s *= scales ? scales[z] : 1.f;
@@ -789,6 +960,15 @@ int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_p
     BASD_RETURN_LAST();
 }
 
+// Test / tuning hook: 1 (default) = Gram launches on the bf16 matrix cores with three-way split operands (fp32 results:
+// syrk_tn_split_kernel); 0 = fp32 MFMA.  Process-wide.
+static int g_gemm_split = 1;
+int basd_gemm_tuning(int split_bf16) {
+    if (split_bf16 != 0 && split_bf16 != 1) return BASD_EINVAL;
+    g_gemm_split = split_bf16;
+    return BASD_OK;
+}
+
 // Split count for the symmetric Gram launch: the grid (tile pairs x splits x matrices) should fill whole
 // rounds of the chip (256 CUs x 3 resident workgroups at this kernel's register budget) -- a 1.3-round
 // grid costs two rounds -- with every split keeping >= 8 k-chunks.  Among (near-)equal fills the smallest
@@ -829,7 +1009,14 @@ int basd_syrk_multi(const void* const* x_ptrs, int dtype, long sb, long sn, long
     GemmOperand X{nullptr, sb, sn, sd, rows_per_batch, 0};
     const int tiles = (cols + BM - 1) / BM, pairs = tiles * (tiles + 1) / 2;
     const dim3 grid(pairs * splits * n_mats);
-    if (dtype == BASD_DTYPE_F32) {
+    if (g_gemm_split && dtype == BASD_DTYPE_F32) {
+        const bool vec = vec_ok && sd == 1 && sb % 4 == 0 && sn % 4 == 0;
+        if (vec) syrk_tn_split_kernel<float, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);
+        else syrk_tn_split_kernel<float, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);
+    } else if (g_gemm_split && dtype == BASD_DTYPE_BF16) {
+        if (sd == 1) syrk_tn_split_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);
+        else syrk_tn_split_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);
+    } else if (dtype == BASD_DTYPE_F32) {
         const bool vec = vec_ok && sd == 1 && sb % 4 == 0 && sn % 4 == 0;
         if (vec) syrk_tn_kernel<float, true><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);
         else syrk_tn_kernel<float, false><<<grid, 256, 0, stream>>>(x_ptrs, X, cols, krows, splits, n_mats, pairs, means, slabs, fold, fold_parts, fold_from);

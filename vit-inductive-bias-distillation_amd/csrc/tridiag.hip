@@ -50,7 +50,7 @@ __device__ __forceinline__ float block_sum_lds(float v, float* scratch, int nw) 
 typedef unsigned tri_u32x4 __attribute__((ext_vector_type(4)));
 typedef float tri_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void granule_store(uint4* p, float a, float b, unsigned tag) {
-    const tri_u32x4 x = {__float_as_uint(a), __float_as_uint(b), tag, 0u};
+    const tri_u32x4 x = {__float_as_uint(a), __float_as_uint(b), tag, __float_as_uint(a) ^ __float_as_uint(b) ^ tag};
     // the trailing s_nop covers the >8-byte store's data-register hazard: hipcc pads nothing after inline asm,
     // and its next instruction may otherwise overwrite x before the store has read it
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(1024) tridiag_kernel(float* __restrict__ A, lo
             for (int r = b_first * TRI_BLK + tid; r < n; r += nthr) {
                 if ((r / TRI_BLK) % P == p) continue;
                 tri_u32x4 g = granule_load(xp + r);
-                while (g.z != tag && budget > 0) {
+                while ((g.z != tag || g.w != (g.x ^ g.y ^ g.z)) && budget > 0) {
                     __builtin_amdgcn_s_sleep(1);
                     --budget;
                     g = granule_load(xp + r);
@@ -2159,9 +2159,14 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
         static std::atomic<unsigned> launches{0};
         const unsigned tag_base = (1u + launches.fetch_add(1, std::memory_order_relaxed) % 0xFFFFFu) << 12;
         const size_t lds = sizeof(float) * 9 * (size_t)n;
-        // a member with one 32-row block keeps only four waves busy in the pass: fewer waves make the barriers
-        // cheaper (n = 384, 12 members: 1.63 ms with 1024 threads, 1.55 with 512, 1.66 with 256)
-        int threads = (P > 1 && (nblk_of(n) + P - 1) / P <= 1) ? 512 : 1024;
+        // Always 1024 threads per member.  A member with one 32-row block keeps only four waves busy in the pass and
+        // 512 threads made its barriers cheaper (n = 384, 12 members: 1.55 ms against 1.63) -- but round 3 found every
+        // workgroup size BELOW 1024 (256, 512, 768; 4, 6 or 12 members) delivering wrong factorisations (status words
+        // clean, granule check words consistent, all members of a matrix on one XCD) when the split-operand Gram launch
+        // runs beside it, 5-10 times in 10, and never with the fp32 Gram launch or alone; 1024 threads: never, under
+        // the same load (test_tridiag_members_under_uneven_load).  Cause not found; the smaller sizes stay reachable
+        // through basd_tridiag_tuning(threads) for whoever wants to hunt it, production never takes them.
+        int threads = 1024;
         if (g_tuning.threads > 0) threads = g_tuning.threads;
         const int lag = g_tuning.lag;
         if (vec && (n & 7) == 0) tridiag_kernel<true, true><<<P * batch_pad, threads, lds, stream>>>(a, a_batch_stride, n, batch, batch_pad, P, d, e, tau, vh, xg, err, tag_base, lag, j_stop, pend);
