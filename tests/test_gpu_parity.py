@@ -503,7 +503,8 @@ def test_rank_readback_is_deferred_only_behind_a_proof():
     for a, b in zip(out["sync"][1], out["auto"][1]):
         assert torch.equal(a, b)
     assert out["sync"][2] == out["auto"][2] and min(out["auto"][2].values()) >= 1
-    assert torch.equal(out["sync"][3], out["auto"][3])
+    # (the two modes take different chain layouts -- one factorisation launch or two -- so d_grass_sq agrees to rounding)
+    torch.testing.assert_close(out["sync"][3], out["auto"][3], rtol=1e-5, atol=0)
 
 
 def test_selector_forward_api_materialises_mixed_tensors(golden):

@@ -26,6 +26,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128;
 
+// ---- split operands: fp32-grade products on the bf16 matrix cores (see syrk_tn_split_kernel) ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// (a, b) -> packed bf16 pieces (hi, mid, lo) with a = hi_a + mid_a + lo_a exactly, likewise b
+__device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    mid = cvt_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
+    lo = cvt_pk_bf16(sa, sb);
+}
+
+
 struct GemmOperand {
     const void* ptr;
     long sb, sn, sd;     // (batch, row-in-batch, column) strides in elements
@@ -232,6 +251,178 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmOperand A, GemmOperand
             s[ni] += __shfl_xor(s[ni], 32, 64);      // the two lane halves hold different rows of one column
         }
         __syncthreads();                             // the K loop is done with the LDS tiles
+        if (hi == 0) {
+            lds[wm * 128 + wn * 64 + col_l] = s[0];
+            lds[wm * 128 + wn * 64 + 32 + col_l] = s[1];
+        }
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N)
+            colsum_part[((long)blockIdx.z * ny + by) * N + n0 + tid] = lds[tid] + lds[128 + tid];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// NT with split operands (see syrk_tn_split_kernel): both tiles are staged as three bf16 planes [row][k], row stride 40
+// bf16 = 80 bytes (20 dwords: the 16 lanes of a ds_read_b128 group land on disjoint bank quads), a lane's MFMA operand
+// is ONE 16-byte read of 8 consecutive k.  Rows map to MFMA lanes directly: store_tile and the column-sum epilogue are
+// those of gemm_nt_kernel.  The strided-operand loader (channel-major teacher tokens: lanes along rows) fetches k in
+// adjacent PAIRS (k0 + 2 (tid >> 7) + 4 q + {0, 1}) so that a pair packs into one 4-byte LDS store per plane.
+// ---------------------------------------------------------------------------
+constexpr int NTS_LD = 40;                       // bf16 elements per LDS row (32 used)
+constexpr int NTS_PLANE = 128 * NTS_LD;          // bf16 elements of one plane of one operand tile
+
+template <bool VEC>
+__device__ __forceinline__ void nts_rows(const GemmOperand& o, int rows_total, int row0, int tid, long (&off)[4]) {
+    if (VEC) {
+        nt_rows<true>(o, rows_total, row0, tid, off);
+    } else {
+        int row = row0 + (tid & 127);
+        if (row >= rows_total) row = rows_total - 1;
+        off[0] = row_off(o, row) + (long)(2 * (tid >> 7)) * o.sd;
+        off[1] = off[2] = off[3] = 0;
+    }
+}
+
+template <typename TA, bool VEC>
+__device__ __forceinline__ void nts_load(const GemmOperand& o, const long (&off)[4], int K, int k0, int tid,
+                                         float (&reg)[4][4]) {
+    if (VEC) {
+        nt_load<TA, true>(o, off, K, k0, tid, reg);
+    } else {
+        const TA* p = (const TA*)o.ptr + off[0] + (long)k0 * o.sd;
+        const int k = k0 + 2 * (tid >> 7);
+        if (k0 + NT_BK <= K) {     // uniform
+#pragma unroll
+            for (int q = 0; q < 16; ++q) reg[q >> 2][q & 3] = to_f32(p[(long)(4 * (q >> 1) + (q & 1)) * o.sd]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int dk = 4 * (q >> 1) + (q & 1);
+                reg[q >> 2][q & 3] = (k + dk < K) ? to_f32(p[(long)dk * o.sd]) : 0.f;
+            }
+        }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void nts_store_lds(unsigned short* __restrict__ tile, int tid, const float (&reg)[4][4]) {
+    if (VEC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = tid + 256 * j;
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(reg[j][0], reg[j][1], h0, m0, l0);
+            split3(reg[j][2], reg[j][3], h1, m1, l1);
+            unsigned short* p = tile + (f >> 3) * NTS_LD + (f & 7) * 4;
+            *(uint2*)(p) = make_uint2(h0, h1);
+            *(uint2*)(p + NTS_PLANE) = make_uint2(m0, m1);
+            *(uint2*)(p + 2 * NTS_PLANE) = make_uint2(l0, l1);
+        }
+    } else {
+        unsigned short* row = tile + (tid & 127) * NTS_LD + 2 * (tid >> 7);
+#pragma unroll
+        for (int pq = 0; pq < 8; ++pq) {
+            unsigned h, m, l;
+            split3(reg[pq >> 1][2 * (pq & 1)], reg[pq >> 1][2 * (pq & 1) + 1], h, m, l);
+            *(unsigned*)(row + 4 * pq) = h;
+            *(unsigned*)(row + 4 * pq + NTS_PLANE) = m;
+            *(unsigned*)(row + 4 * pq + 2 * NTS_PLANE) = l;
+        }
+    }
+}
+
+template <typename TA, bool VEC_A>
+__global__ void __launch_bounds__(256) gemm_nt_split_kernel(GemmOperand A, GemmOperand B, int M, int N, int K,
+                                                            float* __restrict__ C, long ldc, long c_batch_stride,
+                                                            float scale, const float* __restrict__ bias, float beta,
+                                                            float* __restrict__ colsum_part, int nx, int ny) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds16[2 * 3 * NTS_PLANE];
+    unsigned short* tA = lds16;
+    unsigned short* tB = lds16 + 3 * NTS_PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x, by = blockIdx.y;       // XCD-aware decode of 1-D grids: see gemm_nt_kernel
+    if (gridDim.y == 1 && ny > 1) {
+        const int r = bx & 7, s = bx >> 3;
+        bx = s % nx;
+        by = (s / nx) * 8 + r;
+        if (by >= ny) return;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    A.ptr = (const TA*)A.ptr + (long)blockIdx.z * A.batch_stride;
+    B.ptr = (const float*)B.ptr + (long)blockIdx.z * B.batch_stride;
+    C += (long)blockIdx.z * c_batch_stride;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[4][4], rb[4][4];
+    long offa[4], offb[4];
+    nts_rows<VEC_A>(A, M, m0, tid, offa);
+    nts_rows<true>(B, N, n0, tid, offb);
+    nts_load<TA, VEC_A>(A, offa, K, 0, tid, ra);
+    nts_load<float, true>(B, offb, K, 0, tid, rb);
+    const int i = lane & 31, h = lane >> 5;
+    for (int k0 = 0; k0 < K; k0 += NT_BK) {
+        __syncthreads();
+        nts_store_lds<VEC_A>(tA, tid, ra);
+        nts_store_lds<true>(tB, tid, rb);
+        __syncthreads();
+        if (k0 + NT_BK < K) {
+            nts_load<TA, VEC_A>(A, offa, K, k0 + NT_BK, tid, ra);
+            nts_load<float, true>(B, offb, K, k0 + NT_BK, tid, rb);
+        }
+#pragma unroll
+        for (int s16 = 0; s16 < NT_BK / 16; ++s16) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[mi][p] = *(const bf16x8*)(tA + p * NTS_PLANE + (wm * 64 + mi * 32 + i) * NTS_LD + 16 * s16 + 8 * h);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[ni][p] = *(const bf16x8*)(tB + p * NTS_PLANE + (wn * 64 + ni * 32 + i) * NTS_LD + 16 * s16 + 8 * h);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    f32x16 c = acc[mi][ni];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
+                    acc[mi][ni] = c;
+                }
+        }
+    }
+    store_tile(C, ldc, M, N, m0, n0, acc, wm, wn, lane, scale, bias, beta);
+    if (colsum_part) {       // column sums of this row tile of C: see gemm_nt_kernel
+        float* lds = (float*)lds16;
+        const int col_l = lane & 31, hi = lane >> 5;
+        float s[2] = {0.f, 0.f};
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + col_l;
+            const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < M) s[ni] += acc[mi][ni][r] * scale - bv;
+                }
+            s[ni] += __shfl_xor(s[ni], 32, 64);
+        }
+        __syncthreads();
         if (hi == 0) {
             lds[wm * 128 + wn * 64 + col_l] = s[0];
             lds[wm * 128 + wn * 64 + 32 + col_l] = s[1];
@@ -549,23 +740,7 @@ __global__ void __launch_bounds__(256) syrk_tn_kernel(const void* const* __restr
 //   staging threads (4 consecutive columns each, float4 global loads) store conflict-free; the MFMA lane i of 32-block
 //   b therefore holds column 4 i + b, and the epilogue stores C with that map.
 // ---------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int SPLIT_PLANE = (TN_BK / 8) * 128 * 8;       // bf16 elements of one plane of one operand slab
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// (a, b) -> packed bf16 pieces (hi, mid, lo) with a = hi_a + mid_a + lo_a exactly, likewise b
-__device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-    mid = cvt_pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
-    lo = cvt_pk_bf16(sa, sb);
-}
 
 __device__ __forceinline__ void tn_store_lds_split(unsigned short* __restrict__ tile, int t, const float (&reg)[2][4][4],
                                                    const float (&m4)[4]) {
@@ -859,6 +1034,15 @@ static void launch_colsum(const GemmOperand& X, const void* const* ptrs, const v
 extern "C" {
 
 // C[z] (M x N, ldc) = beta * C[z] + scale * A[z] (M x K) * B[z]^T (N x K) - 1 bias^T.
+// Test / tuning hook: 1 (default) = Gram launches and NT products on the bf16 matrix cores with three-way split operands
+// (fp32 results: syrk_tn_split_kernel, gemm_nt_split_kernel); 0 = fp32 MFMA.  Process-wide.
+static int g_gemm_split = 1;
+int basd_gemm_tuning(int split_bf16) {
+    if (split_bf16 != 0 && split_bf16 != 1) return BASD_EINVAL;
+    g_gemm_split = split_bf16;
+    return BASD_OK;
+}
+
 //   A: element (m, k) at a + z*a_batch_stride + (m / a_rows_per_batch)*a_sb + (m % a_rows_per_batch)*a_sn + k*a_sd,
 //      dtype fp32 or bf16.   B: fp32, row-major with leading dimension ldb.  bias (nullable): N floats.
 int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, int a_rows_per_batch,
@@ -875,7 +1059,14 @@ int basd_gemm_nt(const void* a, int a_dtype, long a_sb, long a_sn, long a_sd, in
     // many row tiles x several column tiles: 1-D grid with the XCD-aware decode (see the kernel); else the plain 3-D grid
     const bool xcd = nx > 1 && ny >= 16;
     const dim3 grid = xcd ? dim3(8 * nx * ((ny + 7) / 8), 1, batch) : dim3(nx, ny, batch);
-    if (a_dtype == BASD_DTYPE_F32) {
+    if (g_gemm_split && a_dtype == BASD_DTYPE_F32) {
+        const bool vec = a_sd == 1 && aligned16(a) && a_sb % 4 == 0 && a_sn % 4 == 0 && a_batch_stride % 4 == 0;
+        if (vec) gemm_nt_split_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
+        else gemm_nt_split_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
+    } else if (g_gemm_split && a_dtype == BASD_DTYPE_BF16) {
+        if (a_sd == 1) gemm_nt_split_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
+        else gemm_nt_split_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
+    } else if (a_dtype == BASD_DTYPE_F32) {
         const bool vec = a_sd == 1 && aligned16(a) && a_sb % 4 == 0 && a_sn % 4 == 0 && a_batch_stride % 4 == 0;
         if (vec) gemm_nt_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
         else gemm_nt_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, K, c, ldc, c_batch_stride, scale, bias, beta, colsum_part, nx, ny);
@@ -958,15 +1149,6 @@ int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_p
     else return BASD_EINVAL;
     colsum_final_kernel<<<dim3((cols + 63) / 64, batch), 256, 0, stream>>>(partial, cols, parts, 1.f / rows, mean);
     BASD_RETURN_LAST();
-}
-
-// Test / tuning hook: 1 (default) = Gram launches on the bf16 matrix cores with three-way split operands (fp32 results:
-// syrk_tn_split_kernel); 0 = fp32 MFMA.  Process-wide.
-static int g_gemm_split = 1;
-int basd_gemm_tuning(int split_bf16) {
-    if (split_bf16 != 0 && split_bf16 != 1) return BASD_EINVAL;
-    g_gemm_split = split_bf16;
-    return BASD_OK;
 }
 
 // Split count for the symmetric Gram launch: the grid (tile pairs x splits x matrices) should fill whole
