@@ -879,6 +879,99 @@ __global__ void __launch_bounds__(256) syrk_tn_split_kernel(const void* const* _
         }
 }
 
+// General TN with split operands: gemm_tn_kernel's grid, loaders and splits, syrk_tn_split_kernel's LDS image and MFMA
+// block (column 4 l + e of a slab at position 32 e + l; the epilogue undoes the map on both sides).
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) gemm_tn_split_kernel(GemmOperand A, GemmOperand B, int M, int N, int Krows,
+                                                            int splits, const float* __restrict__ mean_a,
+                                                            const float* __restrict__ mean_b, float* __restrict__ C,
+                                                            long ldc, long c_z_stride, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 3 * SPLIT_PLANE];
+    unsigned short* tA = lds;
+    unsigned short* tB = lds + 3 * SPLIT_PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int bz = blockIdx.z / splits, sp = blockIdx.z - bz * splits;
+    A.ptr = (const T*)A.ptr + (long)bz * A.batch_stride;
+    B.ptr = (const T*)B.ptr + (long)bz * B.batch_stride;
+    C += (long)blockIdx.z * c_z_stride;
+    const int chunks = (Krows + TN_BK - 1) / TN_BK;
+    const int per = (chunks + splits - 1) / splits;
+    const int k_begin = sp * per * TN_BK;
+    int k_end = k_begin + per * TN_BK;
+    if (k_end > Krows) k_end = Krows;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool is_b = tid >= 128;
+    const int t = tid & 127;
+    const GemmOperand& op = is_b ? B : A;
+    const int cols = is_b ? N : M, col0 = is_b ? n0 : m0;
+    const float* mean = is_b ? mean_b : mean_a;
+    unsigned short* tile = is_b ? tB : tA;
+    float reg[2][4][4], m4[4];
+    TnCursor cu;
+    tn_cursor_init(cu, op, k_begin, t);
+    tn_mean4(mean, cols, col0, t, m4);
+    if (k_begin < k_end) tn_load<T, VEC>(op, cu, k_end, cols, k_begin, col0, t, m4, reg);
+    const int i = lane & 31, h = lane >> 5;
+    for (int k0 = k_begin; k0 < k_end; k0 += TN_BK) {
+        __syncthreads();
+        tn_store_lds_split(tile, t, reg, m4);
+        __syncthreads();
+        if (k0 + TN_BK < k_end) {
+            tn_cursor_advance(cu, op);
+            tn_load<T, VEC>(op, cu, k_end, cols, k0 + TN_BK, col0, t, m4, reg);
+        }
+#pragma unroll
+        for (int s16 = 0; s16 < TN_BK / 16; ++s16) {
+            bf16x8 a[2][3], b[2][3];
+            const int o = 2 * s16 + h;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    a[mi][p] = *(const bf16x8*)(tA + p * SPLIT_PLANE + ((o * 128 + (wm * 2 + mi) * 32 + i) << 3));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[ni][p] = *(const bf16x8*)(tB + p * SPLIT_PLANE + ((o * 128 + (wn * 2 + ni) * 32 + i) << 3));
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    f32x16 c = acc[mi][ni];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[ni][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[ni][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[ni][0], c, 0, 0, 0);
+                    acc[mi][ni] = c;
+                }
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + 4 * i + (wn * 2 + ni);
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + (wm * 2 + mi);
+                if (row < M) C[(long)row * ldc + col] = acc[mi][ni][r] * scale;
+            }
+        }
+}
+
 // grid = (tile pairs * 64, n_mats), block 256: one element of a lower tile per thread.
 __global__ void __launch_bounds__(256) syrk_reduce_kernel(const float* __restrict__ slabs, int cols, int splits,
                                                           const float* __restrict__ scales, float* __restrict__ out,
@@ -1108,7 +1201,13 @@ int basd_gemm_tn(const void* a, const void* b, int dtype, long a_sb, long a_sn, 
     const bool vec = dtype == BASD_DTYPE_F32 && a_sd == 1 && b_sd == 1 && aligned16(a) && aligned16(b) &&
                      a_sb % 4 == 0 && a_sn % 4 == 0 && b_sb % 4 == 0 && b_sn % 4 == 0 && a_batch_stride % 4 == 0 &&
                      b_batch_stride % 4 == 0;
-    if (dtype == BASD_DTYPE_F32) {
+    if (g_gemm_split && dtype == BASD_DTYPE_F32) {
+        if (vec) gemm_tn_split_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+        else gemm_tn_split_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+    } else if (g_gemm_split && dtype == BASD_DTYPE_BF16) {
+        if (a_sd == 1 && b_sd == 1) gemm_tn_split_kernel<__hip_bfloat16, true><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+        else gemm_tn_split_kernel<__hip_bfloat16, false><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
+    } else if (dtype == BASD_DTYPE_F32) {
         if (vec) gemm_tn_kernel<float, true><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
         else gemm_tn_kernel<float, false><<<grid, 256, 0, stream>>>(A, B, M, N, krows, splits, mean_a, mean_b, out, out_ld, z_stride, k_scale);
     } else if (dtype == BASD_DTYPE_BF16) {
