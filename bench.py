@@ -334,7 +334,7 @@ def main() -> None:
         if ops.EIG_SOLVER == "tridiag":
             if chain_step:
                 eig_ms, eig_calls = mean_ms(["basd_tridiag_ranked"])
-                n_mats = 2 * L if mod.chain_mode else 2 * L + E
+                n_mats = 2 * L if mod.chain_mode in (1, 2, 3) else 2 * L + E
             else:
                 # kernel-by-kernel layout: every launch of the two entry points, all their matrices
                 eig_ms, eig_calls = mean_ms(["basd_tridiag", "basd_tridiag_ranked"])

@@ -23,6 +23,10 @@ RELEASE_DELAY = int(os.environ.get("BASD_CHAIN_RELEASE_DELAY", "0"))      # mode
 EARLY_LAUNCH = os.environ.get("BASD_CHAIN_EARLY", "0") == "1"      # measured: ranks 0.3 ms earlier, step 0.1 ms LONGER
 EARLY_BUDGET = 1500        # polls of ~1.7 us before the gated kernel gives up (a profiler serialising kernels)
 CERTIFICATE = os.environ.get("BASD_RANK_CERT", "1") != "0"      # the rank certificate kernel (BasdSelectorChain.cert_mirror)
+# Workspace slots per plan: the chain of step i + SLOTS may only start once the tail of step i has finished.  With the rank
+# read-back left to the next call the selector of a step is ~3.4 ms end to end (cfg-2) for a period of ~1.7: two slots made
+# every chain wait ~0.15 ms for the tail of two steps back
+SLOTS = max(2, int(os.environ.get("BASD_CHAIN_SLOTS", "3")))
 SPEC_MARGIN = 8            # eigenvectors computed beyond the previous step's largest rank (the rank may grow a little)
 
 
@@ -72,7 +76,7 @@ class _Slot:
             cos=buf(E * L * K * K), sigma=buf(E * L * K), k_arr=buf(E * L, i32),
             jflags=buf(_lib.query("basd_jacobi_workspace_ints", E * L, ops.MAX_SWEEPS), i32),
         )
-        split = p.mode != 0
+        split = p.mode not in (0, 4)
         b["tri_work"] = buf(_lib.query("basd_tridiag_workspace_bytes", n, 2 * L if split else nmat), torch.uint8)
         b["tri_work_s"] = buf(_lib.query("basd_tridiag_workspace_bytes", n, E), torch.uint8) if split else None
         b["z_ptrs"] = torch.tensor([b["z"].data_ptr() + 4 * l * M_t * n for l in range(L)], dtype=torch.int64).to(dev)
@@ -145,7 +149,7 @@ class SelectorChainPlan:
         # and the factorisation (~10 us).  On a stream of its own it cost 0.4 ms per step (2.43 against 2.03-2.07 ms with the
         # read-back deferred): one more stream among the step's six made launches of unrelated streams wait for each other
         self.cert_stream = self.chain_stream if CERTIFICATE else None
-        self.slots = [_Slot(self), _Slot(self)]
+        self.slots = [_Slot(self) for _ in range(SLOTS)]
         self.turn = 0
         self.hint = 0                      # previous step's largest rank (0: none yet)
         for slot in self.slots:
@@ -172,7 +176,7 @@ class SelectorChainPlan:
     def queue(self, students, teachers, proj_t: torch.Tensor, proj_s_t: torch.Tensor, main_stream: int) -> _Slot:
         """Queue the whole selector of this step; returns the slot whose ``ev_ranks`` / ``mirror`` the host reads."""
         slot = self.slots[self.turn]
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % len(self.slots)
         a = slot.args
         if getattr(self, "_forked", False):
             main_stream, self._forked = None, False
@@ -212,7 +216,7 @@ class SelectorChainPlan:
             _lib.call("basd_event_record", marks["tail_end"], self.tail_stream.cuda_stream)
             TIMING.append(marks)
         slot.used = slot.used or slot.kmax > 0
-        slot.student_status_pending = self.mode != 0
+        slot.student_status_pending = self.mode not in (0, 4)
         return slot
 
     def read_ranks(self, slot: _Slot) -> tuple[list[int], list[int]]:

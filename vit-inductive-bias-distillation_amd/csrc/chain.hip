@@ -202,7 +202,7 @@ int basd_selector_chain_tail(const BasdSelectorChain* a, int kmax, int exact_k) 
     if (!exact_k && !basd_jacobi_lds_square_fits(kmax)) return BASD_EUNSUPPORTED;
     hipStream_t st = a->tail_stream;
     BASD_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_ranks, 0));
-    if (a->mode != 0) BASD_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_student, 0));
+    if (a->mode != 0 && a->mode != 4) BASD_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_student, 0));
     const long nn = (long)n * n, kn = (long)kmax * n, kk = (long)kmax * kmax;
     // matrices [L, 2L + E): centred teacher Grams, then the student Grams
     const float* dz = a->d + (long)L * n;
@@ -261,7 +261,7 @@ int basd_selector_chain(const BasdSelectorChain* a) {
                    a->tau && a->vh && a->tri_work && a->ranks && a->ev_fork && a->ev_student && a->ev_ranks && a->ev_tail);
     const int E = (int)a->E, L = (int)a->L, B = (int)a->B, n_s = (int)a->n_s, n_t = (int)a->n_t;
     const int n = (int)a->d_s, d_t = (int)a->d_t, mode = (int)a->mode;
-    BASD_CHECK_ARG(E > 0 && L > 0 && B > 0 && n > 1 && d_t > 0 && mode >= 0 && mode <= 3);
+    BASD_CHECK_ARG(E > 0 && L > 0 && B > 0 && n > 1 && d_t > 0 && mode >= 0 && mode <= 4);
     const long M_t = (long)B * n_t, M_s = (long)B * n_s;
     // the uncentred Gram is formed on the feature side (layer_selector.py:12-13); the token-side form (:14-15, fewer
     // rows than features) has a different order: not covered here, the caller takes the per-kernel entry points
@@ -300,6 +300,11 @@ int basd_selector_chain(const BasdSelectorChain* a) {
                               0, (int)M_t, n, d_t, 1, a->z + (long)l * M_t * n, n, M_t * n, 1.f, nullptr, 0.f,
                               a->z_sums + (long)l * tiles * n, a->z_means + (long)l * n, cs));
     BASD_MARK(a->tm_proj, cs);
+    if (mode == 4) {       // the student side starts behind the teacher's projection (both are full-chip MFMA launches)
+        BASD_CHECK_ARG(a->ev_tgram != nullptr && ss != cs);
+        BASD_HIP(hipEventRecord((hipEvent_t)a->ev_tgram, cs));
+        BASD_HIP(hipStreamWaitEvent(ss, (hipEvent_t)a->ev_tgram, 0));
+    }
     BASD_TRY(basd_syrk_multi(a->z_ptrs, BASD_DTYPE_F32, 0, n, 1, 1 << 30, (int)M_t, n, L, a->z_means, nullptr,
                              (int)a->t_splits, a->t_slabs, a->grams + (long)L * nn, nn, 1, nullptr, 0, 0, cs));
     BASD_TRY(basd_gram_finish(a->grams + (long)L * nn, a->z_means, n, L, M_t, a->grams, nullptr, cs));
@@ -328,7 +333,7 @@ int basd_selector_chain(const BasdSelectorChain* a) {
         return BASD_OK;
     };
 
-    if (mode == 0) {
+    if (mode == 0 || mode == 4) {
         // ONE factorisation launch over all 2L + E matrices: the student Grams join the teacher's before it
         BASD_TRY(student_grams(ss));
         if (ss != cs) {
