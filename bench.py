@@ -40,6 +40,7 @@ from basd_amd.losses import BASDLoss
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense
+MFMA_BF16_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (the split-operand Gram / GEMM kernels run on it)
 STUDENT_PARAMS = {"cfg1": 5_700_000, "cfg2": 22_050_664, "cfg4": 86_600_000, "cfg5": 86_600_000}
 LABEL_SMOOTHING = {"cfg1": 0.01, "cfg2": 0.001, "cfg4": 0.001, "cfg5": 0.001}
 
@@ -341,8 +342,9 @@ def main() -> None:
                 n_mats = (2 * L + E) / max(eig_calls, 1)
             packed = 256 < d_s <= 384
             kernel_name = ("tridiag_packed_kernel (Householder tridiagonalisation, whole factorisation of one matrix in one "
-                           "CU's registers: upper triangle as packed row pairs; teacher-side launch, the one the host waits "
-                           "for)" if packed else
+                           "CU's registers: upper triangle as packed row pairs; "
+                           + ("teacher-side launch, the one the host waits for)" if mod.chain_mode in (1, 2, 3) else
+                              "one launch over the teacher and student matrices)") if packed else
                            "tridiag_kernel + tridiag_tail2_kernel (Householder tridiagonalisation of the selector's Gram "
                            "matrices: shared stage + register-resident tail stage)")
             note = ("latency-bound, neither an HBM stream nor MFMA work: n - 1 dependent Householder steps, each one pass over "
@@ -435,7 +437,21 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "note": note,
             },
-            "roofline_mfma": {
+            "roofline_mfma": ({
+                # split operands: every fp32-grade multiply-add is SIX bf16 MFMA multiply-adds (hi hi, hi mid, mid hi, mid mid,
+                # hi lo, lo hi of the three-way exact bf16 split); `achieved` counts those, against the dense bf16 peak
+                "kernel": ("syrk_tn_split_kernel (+ syrk_reduce_kernel): centred Gram matrices of the E student layers" if marks else
+                           "syrk_tn_split_kernel (+ syrk_reduce_kernel): the step's symmetric Gram launches (student layers; teacher layers)"),
+                "bound": "mfma", "achieved": 6 * syrk_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                "frac": 6 * syrk_tf / MFMA_BF16_PEAK_TF, "traffic": traffic.get("syrk_tn_kernel"),
+                "traffic_source": traffic_source if traffic.get("syrk_tn_kernel") else None,
+                "launch_ms": syrk_ms, "launches_per_step": syrk_calls, "executed_flops_per_launch": 6 * syrk_flops,
+                "fp32_grade_tflops": syrk_tf, "fp32_mfma_peak_tflops": MFMA_F32_PEAK_TF,
+                "note": "bf16 MFMA (v_mfma_f32_32x32x16_bf16) on three-way split fp32 operands, fp32 accumulation: fp32-grade "
+                        "results at six bf16 multiply-adds each (fp32_grade_tflops = what an fp32 MFMA kernel would have to "
+                        "sustain, against its 157 TF peak); flops counted are the lower-triangular 128x128 tile pairs actually "
+                        "executed; timed inside the step, i.e. while the other streams' kernels share the chip",
+            } if _lib.query("basd_gemm_tuning_get") else {
                 "kernel": "syrk_tn_kernel (+ syrk_reduce_kernel): centred Gram matrices of the E student layers" if marks else
                           "syrk_tn_kernel (+ syrk_reduce_kernel): the step's symmetric Gram launches (student layers; teacher layers)",
                 "bound": "mfma", "achieved": syrk_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
@@ -445,7 +461,7 @@ def main() -> None:
                 "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32); flops counted are the lower-triangular 128x128 tile "
                         "pairs actually executed; timed inside the step, i.e. while the other streams' kernels "
                         "share the chip",
-            },
+            }),
             "roofline_hbm_stream": {
                 "kernel": "colsum_partial_vec_kernel (+ colsum_final_kernel): column means of the E student layers",
                 "bound": "hbm", "achieved": col_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -74,6 +74,7 @@ int basd_colmean(const void* x, int dtype, long sb, long sn, long sd, int rows_p
  * value cut into three bf16 pieces (exact) and the six leading piece products accumulated in fp32 -- fp32-grade results at
  * 2.7x the fp32 MFMA ceiling; 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32). */
 int basd_gemm_tuning(int split_bf16);
+int basd_gemm_tuning_get(void);       /* the current setting */
 
 /* means[z][c] for a DEVICE table of n_mats same-layout matrices (one launch for all extraction layers of
  * layer_selector.py:88-91).  `partial`: n_mats*parts*cols floats of scratch.  vec_ok: caller asserts every base

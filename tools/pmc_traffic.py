@@ -7,6 +7,8 @@ import csv, json, sys, collections
 
 KEYS = {"tridiag_packed_kernel": "tridiag_packed_kernel", "tridiag_kernel": "tridiag_kernel",
         "tridiag_tail2_kernel": "tridiag_tail_kernel", "syrk_tn_kernel": "syrk_tn_kernel",
+        "syrk_tn_split_kernel": "syrk_tn_kernel", "gemm_nt_split_kernel<float, false>": "gemm_nt_kernel",
+        "jacobi_oe_kernel": "jacobi_lds_kernel",
         "colsum_partial_vec_kernel": "colsum_partial_vec_kernel", "gemm_nt_kernel<float, false>": "gemm_nt_kernel",
         "jacobi_lds_kernel<16, 16, 4>": "jacobi_lds_kernel", "student_project_v4_kernel": "student_project_v4_kernel",
         "student_grad_fused_kernel": "student_grad_fused_kernel"}

@@ -32,6 +32,7 @@ SIGNATURES = {
     "basd_jacobi_tuning": [i32],
     "basd_jacobi_ordering": [i32],
     "basd_gemm_tuning": [i32],
+    "basd_gemm_tuning_get": [],
     "basd_jacobi_onesided": [vp, i64, i32, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp],
     "basd_sort_extract": [vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp],
     "basd_tridiag_workspace_bytes": [i32, i32],

@@ -1130,6 +1130,7 @@ extern "C" {
 // Test / tuning hook: 1 (default) = Gram launches and NT products on the bf16 matrix cores with three-way split operands
 // (fp32 results: syrk_tn_split_kernel, gemm_nt_split_kernel); 0 = fp32 MFMA.  Process-wide.
 static int g_gemm_split = 1;
+int basd_gemm_tuning_get(void) { return g_gemm_split; }
 int basd_gemm_tuning(int split_bf16) {
     if (split_bf16 != 0 && split_bf16 != 1) return BASD_EINVAL;
     g_gemm_split = split_bf16;
