@@ -507,6 +507,35 @@ def test_rank_readback_is_deferred_only_behind_a_proof():
     torch.testing.assert_close(out["sync"][3], out["auto"][3], rtol=1e-5, atol=0)
 
 
+def test_bf16_multilayer_teacher_rounds_the_mixing_weights_like_the_reference():
+    """layer_selector.py:110 casts the mixing weights to the token dtype: with a bf16 multi-layer teacher they are bf16
+    values.  Same here (value only: the adjoint of a cast is the identity); the loss agrees with the oracle run on the same
+    bf16 inputs to bf16 accuracy (the reference also MIXES in bf16, which this library does in fp32)."""
+    shape, seed = S.SMALL["vit"]
+    mod = _module(shape, 0.01)
+    inp = synth.make_inputs(shape, seed, dtype=torch.bfloat16)
+    student = {l: inp.student[l].to(DEV).requires_grad_(True) for l in mod.token_layers}
+    teacher = {k: v.to(DEV) for k, v in inp.teacher.items()}
+    attn = {k: v.to(DEV) for k, v in inp.attn.items()}
+    loss = mod(inp.logits.to(DEV), inp.targets.to(DEV), student, teacher, attn)
+    loss.backward()
+    mix = mod.last_components["mix"]
+    assert torch.equal(mix, mix.to(torch.bfloat16).float()), "weights must be bf16-representable"
+    assert mod.layer_selector.log_temperatures.grad is not None and torch.isfinite(mod.layer_selector.log_temperatures.grad).all()
+    # the oracle on the widened inputs (torch has no bf16 linalg on the CPU): same ranks, loss to the accuracy of the rounding
+    torch.manual_seed(42)
+    state = O.SelectorState.create(shape.points, shape.d_s, shape.d_t)
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.01)
+    ref, trace = O.basd_forward(state, crit, mod.token_layers, shape.n_s, shape.has_cls, inp.logits, inp.targets,
+                                {k: v.float() for k, v in inp.student.items()}, {k: v.float() for k, v in inp.teacher.items()},
+                                {k: v.float() for k, v in inp.attn.items()})
+    assert mod.layer_selector.subspace_ranks == trace.selector.ranks
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-2)
+    exact = torch.stack([trace.selector.mix_weights[l] for l in mod.token_layers])
+    assert torch.equal(mix.cpu(), exact.to(torch.bfloat16).float()) or \
+        torch.allclose(mix.cpu(), exact.to(torch.bfloat16).float(), atol=2 ** -8)      # a weight may sit on a rounding boundary
+
+
 def test_selector_forward_api_materialises_mixed_tensors(golden):
     """GrassmannianLayerSelector.forward keeps the reference's return contract (dicts of mixed tokens and
     attention maps); values against the reference's own outputs."""

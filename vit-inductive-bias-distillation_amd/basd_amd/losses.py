@@ -950,7 +950,12 @@ class GrassmannianLayerSelector(nn.Module):
         d = self._distances(students, keys, teachers)
         self._last_d_grass_sq = d.detach()                  # layer_selector.py:105, kept for ``last_components``
         tau = self.temperatures.float()
-        return torch.softmax(-d / tau.unsqueeze(1), dim=1)
+        w = torch.softmax(-d / tau.unsqueeze(1), dim=1)
+        if teachers[0].dtype != torch.float32:
+            # layer_selector.py:110: the weights are cast to the token dtype before they mix the layers; autograd's adjoint of
+            # a cast is the identity, so the rounding is applied to the VALUE only (the mixing itself stays in fp32 here)
+            w = w + (w.to(teachers[0].dtype).float() - w).detach()
+        return w
 
     @torch.no_grad()
     def _mix_for_student_layer(
