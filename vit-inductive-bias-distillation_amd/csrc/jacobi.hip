@@ -931,9 +931,10 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
         }
     }
 
-    // ---- the same with 8 lanes per pair for long columns at about one matrix per CU (cfg-5: 256 cores of 144 x 144):
-    // what counts there is the latency of one round, and half the elements per lane shorten it ----
-    if (!stacked && !n_arr && rows_tot > 96 && rows_tot <= 160 && n_even <= 160 &&
+    // ---- (round-robin ordering only) the same with 8 lanes per pair for long columns at about one matrix per CU (cfg-5:
+    // 256 cores of 144 x 144): what counts there is the latency of one round, and half the elements per lane shorten it.
+    // The odd-even solver below beats it there as well (cfg-5: 6.54 -> 5.9 ms per step) ----
+    if (g_jacobi_ordering == 0 && !stacked && !n_arr && rows_tot > 96 && rows_tot <= 160 && n_even <= 160 &&
         (lanes == 8 || (lanes == 0 && batch >= 128 && batch <= 320))) {
         const size_t lds8p = (size_t)n_even * (8 * 20 + 16 + 2) * sizeof(float);
         if (lds8p <= BASD_JACOBI_LDS_LIMIT) {
