@@ -2164,8 +2164,13 @@ static int tridiag_impl(float* a, long a_batch_stride, int n, int batch, float* 
         // workgroup size BELOW 1024 (256, 512, 768; 4, 6 or 12 members) delivering wrong factorisations (status words
         // clean, granule check words consistent, all members of a matrix on one XCD) when the split-operand Gram launch
         // runs beside it, 5-10 times in 10, and never with the fp32 Gram launch or alone; 1024 threads: never, under
-        // the same load (test_tridiag_members_under_uneven_load).  Cause not found; the smaller sizes stay reachable
-        // through basd_tridiag_tuning(threads) for whoever wants to hunt it, production never takes them.
+        // the same load (test_tridiag_members_under_uneven_load; 800 factorisations of orders 384 and 768 beside either
+        // split-operand kernel: none wrong).  What was ruled out: torn granules (a check word travels with them), members on
+        // different XCDs (HW_REG_XCC_ID recorded: one XCD per matrix), stale LDS, barriers that leave VMEM in flight (all
+        // replaced by __syncthreads: same), wave priority, the LDS footprint of the neighbour (fp32 Gram launch padded to
+        // the same 48 KB: clean); the fp32 MFMA kernels, the LDS / VALU-bound Jacobi and HBM streams as neighbours: clean.
+        // Cause not found; the smaller sizes stay reachable through basd_tridiag_tuning(threads) for whoever wants to hunt
+        // it, production never takes them.
         int threads = 1024;
         if (g_tuning.threads > 0) threads = g_tuning.threads;
         const int lag = g_tuning.lag;
