@@ -373,6 +373,27 @@ def test_selector_chain_layouts_agree_with_the_reference(golden, mode):
     assert list(mod._chain_plans.values())[0].mode == mode
 
 
+def test_selector_tails_on_two_streams(golden, monkeypatch):
+    """Teachers of high rank: alternate steps queue the selector's tail on a second stream (``chain.TAIL_STREAMS``; taken
+    by itself from rank 96 on).  Forced here at the golden's shapes: ranks, loss and d_grass_sq of four consecutive steps
+    (every slot, both streams) against the reference's."""
+    from basd_amd import chain
+    monkeypatch.setattr(chain, "TAIL_STREAMS", 2)
+    g = golden("baseline_scalars.npz")
+    shape = synth.CONFIGS["cfg2"]
+    mod = _module(shape, 0.001)
+    inp = synth.make_inputs(shape, 1234, batch=8, device=DEV, strided=True)
+    seen = set()
+    for _ in range(4):
+        loss = mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
+        assert list(mod.layer_selector.subspace_ranks.values()) == list(g["cfg2_s1234_b8_ranks"])
+        np.testing.assert_allclose(loss.item(), g["cfg2_s1234_b8_loss"], rtol=1e-4)
+        np.testing.assert_allclose(_d_grass_sq(mod), g["cfg2_s1234_b8_d_grass_sq"], rtol=2e-4)
+        for plan in mod._chain_plans.values():
+            seen.update(slot.tail_stream.cuda_stream for slot in plan.slots if slot.d_out is not None)
+    assert len(seen) == 2, "both tail streams must have been used"
+
+
 def test_principal_angle_distance_cfg2_full_batch_vs_oracle():
     """The same at the headline size (B = 256, kmax 48, n 384): no reference value exists at this size for d (the golden
     holds the loss), so the oracle's selector is run on the CPU for the same inputs (seconds: it needs the Gram route,

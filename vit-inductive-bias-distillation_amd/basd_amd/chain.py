@@ -27,6 +27,13 @@ CERTIFICATE = os.environ.get("BASD_RANK_CERT", "1") != "0"      # the rank certi
 # read-back left to the next call the selector of a step is ~3.4 ms end to end (cfg-2) for a period of ~1.7: two slots made
 # every chain wait ~0.15 ms for the tail of two steps back
 SLOTS = max(2, int(os.environ.get("BASD_CHAIN_SLOTS", "3")))
+# The tails of consecutive steps are independent.  A teacher of high rank makes the tail long (rank 160: 4 ms of latency-bound
+# launches in four workgroups) and, on one stream, the period: alternate steps then queue theirs on a second stream (4.16 ->
+# 2.95 ms per step).  At rank 48 the tail (1.2 ms) fits the period and the extra stream COSTS 0.3 ms (1.63 -> 1.92: one more
+# stream among the step's six makes unrelated launches wait for each other), so it is only taken from TAIL_SPLIT_RANK on.
+# BASD_TAIL_STREAMS = 1 / 2 pins the choice.
+TAIL_STREAMS = int(os.environ.get("BASD_TAIL_STREAMS", "0"))
+TAIL_SPLIT_RANK = 96
 SPEC_MARGIN = 8            # eigenvectors computed beyond the previous step's largest rank (the rank may grow a little)
 
 
@@ -158,6 +165,7 @@ class SelectorChainPlan:
             a.s_dtype, (a.s_sb, a.s_sn, a.s_sd) = ops._dtype_code(s), s.stride()
             a.chain_stream = self.chain_stream.cuda_stream
             a.student_stream = self.student_stream.cuda_stream
+            slot.tail_stream = self.tail_stream
             a.tail_stream = self.tail_stream.cuda_stream
 
     def speculative_kmax(self) -> int:
@@ -187,8 +195,15 @@ class SelectorChainPlan:
         a.proj_t, a.proj_s_t = proj_t.data_ptr(), proj_s_t.data_ptr()
         a.main_stream = main_stream
         a.ev_slot_free = slot.ev_tail if slot.used else None
+        two = TAIL_STREAMS == 2 or (TAIL_STREAMS == 0 and self.hint >= TAIL_SPLIT_RANK)
+        if two and self.fact_stream is not None and not self.early:
+            self._tail_turn = getattr(self, "_tail_turn", 0) ^ 1
+            slot.tail_stream = self.fact_stream if self._tail_turn else self.tail_stream
+        else:
+            slot.tail_stream = self.tail_stream
+        a.tail_stream = slot.tail_stream.cuda_stream
         slot.d_out = torch.empty((self.E, self.L), device=self.device, dtype=torch.float32)
-        slot.d_out.record_stream(self.tail_stream)
+        slot.d_out.record_stream(slot.tail_stream)
         a.d_out = slot.d_out.data_ptr()
         slot.kmax = a.kmax = self.speculative_kmax()
         if self.early:
@@ -213,7 +228,7 @@ class SelectorChainPlan:
             marks["student_end"] = _event(True)
             _lib.call("basd_event_record", marks["student_end"], self.student_stream.cuda_stream)
             marks["tail_end"] = _event(True)        # behind whatever of the tail this call queued
-            _lib.call("basd_event_record", marks["tail_end"], self.tail_stream.cuda_stream)
+            _lib.call("basd_event_record", marks["tail_end"], slot.tail_stream.cuda_stream)
             TIMING.append(marks)
         slot.used = slot.used or slot.kmax > 0
         slot.student_status_pending = self.mode not in (0, 4)
