@@ -220,6 +220,11 @@ int basd_mp_rank(const float* vals_desc, int n, int batch, double factor, int ca
 int basd_grassmann_distance(const float* colnorm, int stride, const int* k_arr, const float* sw, int sw_stride,
                             const int* sw_index, int items, float* d_out, float* theta_out, hipStream_t stream);
 
+/* The same for matrices that were zero-padded to a common order n_valid (everything outside the leading k x k block zero,
+ * basd_selector_chain_tail): colnorm holds n_valid values per item in any order, the k largest are the cosines. */
+int basd_grassmann_distance_padded(const float* colnorm, int stride, int n_valid, const int* k_arr, const float* sw,
+                                   int sw_stride, const int* sw_index, int items, float* d_out, hipStream_t stream);
+
 int basd_sqrt_clamp(const float* in, float* out, long count, hipStream_t stream);
 
 /* Both Grams of the projected teacher tokens z = tokens proj_t^T (layer_selector.py:72 -> :13 and :35) from the centred

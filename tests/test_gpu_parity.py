@@ -430,6 +430,28 @@ def test_speculative_tail_follows_the_rank():
         np.testing.assert_allclose(d, d_ref, rtol=3e-4, err_msg=str(r_t))
 
 
+def test_selector_tail_at_teacher_ranks_near_160():
+    """Teachers of rank ~160 (what random-init / real ResNet-50 features give at D_s = 384): from the second step on the
+    tail is sized by a hint past 96 -- the principal-angle matrices are zero-padded to the common order and take the
+    register-resident solver, alternate steps use the second tail stream.  Ranks and d_grass_sq against the oracle while
+    the rank moves up and down (150 -> 165 -> 120 -> 160)."""
+    shape = synth.CONFIGS["cfg2"]
+    mod = _module(shape, 0.001)
+    torch.manual_seed(42)
+    state = O.SelectorState.create(shape.points, shape.d_s, shape.d_t)
+    import dataclasses
+    for r_t in (150, 165, 120, 160):
+        sh = dataclasses.replace(shape, r_t=r_t)
+        inp = synth.make_inputs(sh, 900 + r_t, batch=16, device=DEV, strided=True)
+        mod(inp.logits, inp.targets, inp.student, inp.teacher, inp.attn)
+        d = _d_grass_sq(mod)
+        cpu = synth.make_inputs(sh, 900 + r_t, batch=16)
+        ranks, d_ref = _oracle_selector(state, cpu, mod.token_layers)
+        assert mod.layer_selector.subspace_ranks == ranks, r_t
+        assert min(ranks.values()) > 100, ranks
+        np.testing.assert_allclose(d, d_ref, rtol=3e-4, err_msg=str(r_t))
+
+
 def test_bf16_inputs_cfg5_shapes():
     """cfg-5 (bf16 features): tokens are consumed in place as bf16 and widened inside the kernels; the parity
     target is the fp32 oracle on the same bf16-rounded values (the reference itself has no runnable

@@ -53,6 +53,7 @@ SIGNATURES = {
     "basd_tridiag_eigenvectors": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp],
     "basd_mp_rank": [vp, i32, i32, f64, i32, vp, vp, vp],
     "basd_grassmann_distance": [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp],
+    "basd_grassmann_distance_padded": [vp, i32, i32, vp, vp, i32, vp, i32, vp, vp],
     "basd_selector_tail": [vp] * 10 + [i32, i32, i32, i32] + [vp] * 14 + [vp],
     "basd_sqrt_clamp": [vp, vp, i64, vp],
     "basd_gram_finish": [vp, vp, i32, i32, i64, vp, vp, vp],

@@ -173,7 +173,9 @@ class SelectorChainPlan:
         if self.hint <= 0:
             return 0
         k = min(self.hint + SPEC_MARGIN, self.kmax_cap)
-        return k if _lib.query("basd_jacobi_lds_square_fits", k) else 0
+        if _lib.query("basd_jacobi_lds_square_fits", k) or (k >= 96 and _lib.query("basd_jacobi_plain4_fits", k)):
+            return k
+        return 0
 
     def fork(self, main_stream: int) -> None:
         """Mark the point of the caller's stream the NEXT ``queue`` may start behind (its inputs are ready there); work the

@@ -114,6 +114,18 @@ __global__ void __launch_bounds__(256) rank_certificate_kernel(const float* __re
     }
 }
 
+// Principal-angle matrices of per-item order k = k_arr[item] inside a common kmax x kmax storage: everything outside the
+// leading k x k block is zeroed, so that a fixed-order solver may take them (the singular values are those of the block
+// plus kmax - k exact zeros).  grid = items, block = 256.
+__global__ void __launch_bounds__(256) chain_mask_cos_kernel(float* __restrict__ cos, int kmax, const int* __restrict__ k_arr) {
+    const int k = k_arr[blockIdx.x];
+    float* c = cos + (long)blockIdx.x * kmax * kmax;
+    for (int idx = threadIdx.x; idx < kmax * kmax; idx += 256) {
+        const int i = idx / kmax, j = idx - i * kmax;
+        if (i >= k || j >= k) c[idx] = 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(256) debug_fill_lds_kernel(unsigned pattern, int words) {
     extern __shared__ unsigned fill_words[];
     for (int i = threadIdx.x; i < words; i += 256) fill_words[i] = pattern;
@@ -199,7 +211,7 @@ int basd_selector_chain_tail(const BasdSelectorChain* a, int kmax, int exact_k) 
                    a->k_arr && a->sw_index && a->jflags && a->ranks && a->proj_s_t);
     const int E = (int)a->E, L = (int)a->L, n = (int)a->d_s;
     BASD_CHECK_ARG(E > 0 && L > 0 && kmax > 0 && kmax <= n && kmax <= (int)a->kmax_cap);
-    if (!exact_k && !basd_jacobi_lds_square_fits(kmax)) return BASD_EUNSUPPORTED;
+    if (!exact_k && !basd_jacobi_lds_square_fits(kmax) && !(kmax >= 96 && basd_jacobi_plain4_fits(kmax))) return BASD_EUNSUPPORTED;
     hipStream_t st = a->tail_stream;
     BASD_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_ranks, 0));
     if (a->mode != 0 && a->mode != 4) BASD_HIP(hipStreamWaitEvent(st, (hipEvent_t)a->ev_student, 0));
@@ -229,9 +241,20 @@ int basd_selector_chain_tail(const BasdSelectorChain* a, int kmax, int exact_k) 
     }
     const int items = E * L;
     basd::chain_k_arr_kernel<<<(items + 255) / 256, 256, 0, st>>>(a->ranks, L, items, kmax, a->k_arr);
-    BASD_TRY(basd_jacobi_onesided(a->cos, kk, kmax, kmax, kmax, items, exact_k ? nullptr : a->k_arr, a->sigma, kmax, 20,
-                                  0.f, a->jflags, nullptr, st));
-    BASD_TRY(basd_grassmann_distance(a->sigma, kmax, a->k_arr, a->sw, kmax, a->sw_index, items, a->d_out, nullptr, st));
+    if (!exact_k && kmax >= 96 && basd_jacobi_plain4_fits(kmax)) {
+        // large speculative orders (teachers of rank ~100-190): the per-matrix-order solver runs a pair per DPP row (1.4 us
+        // per round at 168 x 168, four workgroups in all); zero-padded to the common order the matrices take the
+        // register-resident odd-even solver (4 lanes per pair), and the distance kernel sorts all kmax values
+        basd::chain_mask_cos_kernel<<<items, 256, 0, st>>>(a->cos, kmax, a->k_arr);
+        BASD_TRY(basd_jacobi_onesided(a->cos, kk, kmax, kmax, kmax, items, nullptr, a->sigma, kmax, 20, 0.f, a->jflags,
+                                      nullptr, st));
+        BASD_TRY(basd_grassmann_distance_padded(a->sigma, kmax, kmax, a->k_arr, a->sw, kmax, a->sw_index, items, a->d_out,
+                                                st));
+    } else {
+        BASD_TRY(basd_jacobi_onesided(a->cos, kk, kmax, kmax, kmax, items, exact_k ? nullptr : a->k_arr, a->sigma, kmax, 20,
+                                      0.f, a->jflags, nullptr, st));
+        BASD_TRY(basd_grassmann_distance(a->sigma, kmax, a->k_arr, a->sw, kmax, a->sw_index, items, a->d_out, nullptr, st));
+    }
     BASD_HIP(hipEventRecord((hipEvent_t)a->ev_tail, st));
     return BASD_OK;
 }

@@ -951,7 +951,7 @@ int basd_jacobi_onesided(float* W, long batch_stride, int rows_dot, int rows_tot
 
     // ---- register-resident, odd-even ordering: plain matrices in batches (the transposed Procrustes cores) ----
     if (g_jacobi_ordering == 1 && !stacked && !n_arr && n_even >= 8 && rows_tot == rows_dot &&
-        (lanes == 0 || lanes == 4) && (g_jacobi_lanes == 4 || (batch >= 128 && n_even >= 40))) {
+        (lanes == 0 || lanes == 4) && (g_jacobi_lanes == 4 || (batch >= 128 && n_even >= 40) || n_even >= 96)) {
         static const int o_epl[] = {8, 16, 24, 36, 50};
         int e4 = 0;
         for (int e : o_epl)

@@ -34,14 +34,16 @@ __global__ void __launch_bounds__(256) grassmann_distance_kernel(const float* __
                                                                  const float* __restrict__ sw, int sw_stride,
                                                                  const int* __restrict__ sw_index,
                                                                  float* __restrict__ d_out,
-                                                                 float* __restrict__ theta_out) {
+                                                                 float* __restrict__ theta_out, int n_valid) {
     __shared__ float key[1024];
     __shared__ float red[32];
     const int m = blockIdx.x, tid = threadIdx.x;
     const int k = k_arr[m];
+    // n_valid > 0: the item's matrix was zero-padded to a common order -- sort all n_valid values, use the leading k
+    const int nv = n_valid > 0 ? n_valid : k;
     int np2 = 1;
-    while (np2 < k) np2 <<= 1;
-    for (int i = tid; i < np2; i += 256) key[i] = i < k ? colnorm[(long)m * stride + i] : -1.f;
+    while (np2 < nv) np2 <<= 1;
+    for (int i = tid; i < np2; i += 256) key[i] = i < nv ? colnorm[(long)m * stride + i] : -1.f;
     __syncthreads();
     for (int kk = 2; kk <= np2; kk <<= 1)
         for (int j = kk >> 1; j > 0; j >>= 1) {
@@ -110,7 +112,16 @@ int basd_mp_rank(const float* vals_desc, int n, int batch, double factor, int ca
 int basd_grassmann_distance(const float* colnorm, int stride, const int* k_arr, const float* sw, int sw_stride,
                             const int* sw_index, int items, float* d_out, float* theta_out, hipStream_t stream) {
     BASD_CHECK_ARG(colnorm && k_arr && sw && sw_index && d_out && items > 0 && stride > 0 && stride <= 1024);
-    grassmann_distance_kernel<<<items, 256, 0, stream>>>(colnorm, stride, k_arr, sw, sw_stride, sw_index, d_out, theta_out);
+    grassmann_distance_kernel<<<items, 256, 0, stream>>>(colnorm, stride, k_arr, sw, sw_stride, sw_index, d_out, theta_out, 0);
+    BASD_RETURN_LAST();
+}
+
+int basd_grassmann_distance_padded(const float* colnorm, int stride, int n_valid, const int* k_arr, const float* sw,
+                                   int sw_stride, const int* sw_index, int items, float* d_out, hipStream_t stream) {
+    BASD_CHECK_ARG(colnorm && k_arr && sw && sw_index && d_out && items > 0 && stride > 0 && n_valid > 0 &&
+                   n_valid <= stride && stride <= 1024);
+    grassmann_distance_kernel<<<items, 256, 0, stream>>>(colnorm, stride, k_arr, sw, sw_stride, sw_index, d_out, nullptr,
+                                                         n_valid);
     BASD_RETURN_LAST();
 }
 
