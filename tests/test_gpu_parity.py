@@ -542,6 +542,22 @@ def test_rank_readback_is_deferred_only_behind_a_proof():
         out[mode] = (loss.item(), [leaves[l].grad.clone() for l in mod.token_layers], ranks,
                      mod.last_components["d_grass_sq"].clone(), deferred)
     assert out["sync"][4] == 0 and out["auto"][4] == 2, (out["sync"][4], out["auto"][4])
+    # a pending read-back must not keep the step's token tensors alive: one more deferred step, then look at
+    # what the pending closure still references
+    loss = mod(inp.logits, inp.targets, leaves, inp.teacher, inp.attn)
+    pending = mod.layer_selector._pending_tail
+    assert pending is not None
+    ptrs = {t.data_ptr() for t in list(inp.teacher.values()) + [leaves[l] for l in mod.token_layers]}
+
+    def tensors_in(obj, depth=0):
+        if isinstance(obj, torch.Tensor):
+            yield obj
+        elif isinstance(obj, (list, tuple)) and depth < 3:
+            for x in obj:
+                yield from tensors_in(x, depth + 1)
+    held = [t for c in pending.__closure__ for t in tensors_in(c.cell_contents) if t.data_ptr() in ptrs]
+    assert not held, "the deferred read-back references input tensors"
+    mod.layer_selector.finish_pending()
     assert out["sync"][0] == out["auto"][0]
     for a, b in zip(out["sync"][1], out["auto"][1]):
         assert torch.equal(a, b)

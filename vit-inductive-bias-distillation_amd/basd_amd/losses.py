@@ -1284,6 +1284,18 @@ class BASDLoss(nn.Module):
             slot = plan.queue(xs, teachers, proj_t, sel._proj_s_transposed(), main.cuda_stream)
             ops.trace("chains_queued")
 
+        # the step's inputs, for the two redo paths below; dropped when the read-back is left to the next call, so that a
+        # pending read-back does not keep a whole step's token tensors alive (a failed factorisation is then not redone:
+        # nothing of that step's loss depended on it)
+        held = [xs, teachers]
+        n_layers = len(students)
+
+        def lost_step(why: str) -> None:
+            import warnings
+            warnings.warn(f"basd_selector_chain: {why}; the selector of that step is not redone (its inputs are gone): "
+                          "subspace_ranks keeps its previous values, d_grass_sq of that step is NaN", RuntimeWarning)
+            comp["d_grass_sq"] = torch.full((n_layers, 1), float("nan"), device=main.device)
+
         def complete():
             nonlocal slot
             ranks, status = plan.read_ranks(slot)
@@ -1295,16 +1307,20 @@ class BASDLoss(nn.Module):
                 warnings.warn("basd_selector_chain: the early-launched factorisation timed out waiting for its input; "
                               "queueing it behind its input for the rest of this process", RuntimeWarning)
                 plan.early = False
+                if held[0] is None:
+                    return lost_step("an early-launched factorisation timed out")
                 torch.cuda.synchronize(main.device)
-                slot = plan.queue(xs, teachers, proj_t, sel._proj_s_transposed(), main.cuda_stream)
+                slot = plan.queue(held[0], held[1], proj_t, sel._proj_s_transposed(), main.cuda_stream)
                 ranks, status = plan.read_ranks(slot)
             if status[0]:       # (words 6, 7 may carry clock readings: BASD_TRIDIAG_CLOCKS)
                 # workgroups sharing a matrix lost each other (bounded spin): degrade, do not die -- the selector of
                 # THIS step once more with one workgroup per matrix, and keep that setting
                 _single_member_mode("workgroups sharing a matrix timed out waiting for each other "
                                     f"(device oversubscribed?) [{status}]")
+                if held[0] is None:
+                    return lost_step("workgroups sharing a matrix timed out waiting for each other")
                 torch.cuda.synchronize(main.device)
-                slot = plan.queue(xs, teachers, proj_t, sel._proj_s_transposed(), main.cuda_stream)
+                slot = plan.queue(held[0], held[1], proj_t, sel._proj_s_transposed(), main.cuda_stream)
                 ranks, status = plan.read_ranks(slot)
                 if status[0]:
                     raise TridiagGiveUp(f"basd_tridiag: the factorisation failed with one workgroup per matrix [{status}]")
@@ -1327,6 +1343,7 @@ class BASDLoss(nn.Module):
             complete()
         else:
             self.readback_deferred_steps += 1
+            held[0] = held[1] = None
             # deferred: this step's ranks are read by the next forward or by the first reader of ``subspace_ranks``;
             # the PREVIOUS step's now, with this step already queued (its rank kernel finished long ago -- if not,
             # this wait is the back-pressure that keeps the host at most one step ahead)
