@@ -2,7 +2,7 @@
 (layer_selector.py:69-74), teacher subspaces (:131-138), principal angles and d_grass_sq (:86-105) -- queued by ONE
 library call into a persistent, shape-keyed workspace.
 
-A plan owns two slots of device buffers (the tail of step i may still read its factorisation while step i + 1 writes
+A plan owns a few slots of device buffers (``SLOTS``: the tail of step i may still read its factorisation while step i + 1 writes
 the next one), the events that order the three streams, the pinned host words the rank kernel writes, and one
 pre-filled argument block per slot; a step only patches the input pointers.  No ``torch.empty``, no Python event
 objects and a single FFI call on the path in front of the chain the host waits for.
