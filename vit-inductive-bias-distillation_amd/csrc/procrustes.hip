@@ -1472,6 +1472,91 @@ int basd_teacher_center_multi(const void* const* tok_ptrs, int dtype, const floa
     BASD_RETURN_LAST();
 }
 
+// The same for fp32 tokens on the teacher's own grid with 16-byte aligned rows (ViT teachers: cfg-4): a thread owns FOUR
+// consecutive features, the layers are read four at a time with all loads in flight before the first use (the scalar form
+// issues one 4-byte load per layer and waits for it: 2.5 TB/s over 24 layers of 103 MB).  Falls back to the scalar form
+// inside the launch when a layer's base pointer is not 16-byte aligned (wave-uniform).
+__global__ void __launch_bounds__(256) teacher_mix_stream_v4_kernel(
+    const void* const* __restrict__ tok_ptrs, const float* __restrict__ mix, int L, int G, long sb, long sn, int n, int D,
+    const float* __restrict__ omega_t, float* __restrict__ Tc, float* __restrict__ chunk_sum) {
+    const int chunk = blockIdx.x, b = blockIdx.y, B = gridDim.y, tid = threadIdx.x;
+    const int j_lo = chunk * TCS_ROWS, j_hi = j_lo + TCS_ROWS < n ? j_lo + TCS_ROWS : n;
+    bool aligned = true;
+    for (int l = 0; l < L; ++l) aligned = aligned && (((uintptr_t)tok_ptrs[l]) & 15) == 0;
+    if (!aligned) {       // uniform over the launch
+        for (int d = tid; d < D; d += 256) {
+            float musum[TCM_G] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = j_lo; j < j_hi; ++j) {
+                const long o0 = b * sb + (long)j * sn + d;
+                float v[TCM_G] = {0.f, 0.f, 0.f, 0.f};
+                for (int l = 0; l < L; ++l) {
+                    const float x = ldg_f32((const BASD_GLOBAL_AS float*)tok_ptrs[l] + o0);
+#pragma unroll
+                    for (int g = 0; g < TCM_G; ++g)
+                        if (g < G) v[g] = fmaf(mix[g * L + l], x, v[g]);
+                }
+#pragma unroll
+                for (int g = 0; g < TCM_G; ++g)
+                    if (g < G) {
+                        Tc[(((long)g * B + b) * n + j) * D + d] = v[g];
+                        musum[g] = fmaf(omega_t[((long)g * B + b) * n + j], v[g], musum[g]);
+                    }
+            }
+#pragma unroll
+            for (int g = 0; g < TCM_G; ++g)
+                if (g < G) chunk_sum[(((long)chunk * G + g) * B + b) * D + d] = musum[g];
+        }
+        return;
+    }
+    for (int d = 4 * tid; d < D; d += 1024) {
+        float4 musum[TCM_G];
+#pragma unroll
+        for (int g = 0; g < TCM_G; ++g) musum[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = j_lo; j < j_hi; ++j) {
+            const long o0 = b * sb + (long)j * sn + d;
+            float4 v[TCM_G];
+#pragma unroll
+            for (int g = 0; g < TCM_G; ++g) v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int l = 0;
+            for (; l + 4 <= L; l += 4) {
+                float4 x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = ld4f((const BASD_GLOBAL_AS float*)tok_ptrs[l + q] + o0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int g = 0; g < TCM_G; ++g)
+                        if (g < G) {
+                            const float m = mix[g * L + l + q];
+                            v[g].x = fmaf(m, x[q].x, v[g].x); v[g].y = fmaf(m, x[q].y, v[g].y);
+                            v[g].z = fmaf(m, x[q].z, v[g].z); v[g].w = fmaf(m, x[q].w, v[g].w);
+                        }
+            }
+            for (; l < L; ++l) {
+                const float4 x = ld4f((const BASD_GLOBAL_AS float*)tok_ptrs[l] + o0);
+#pragma unroll
+                for (int g = 0; g < TCM_G; ++g)
+                    if (g < G) {
+                        const float m = mix[g * L + l];
+                        v[g].x = fmaf(m, x.x, v[g].x); v[g].y = fmaf(m, x.y, v[g].y);
+                        v[g].z = fmaf(m, x.z, v[g].z); v[g].w = fmaf(m, x.w, v[g].w);
+                    }
+            }
+#pragma unroll
+            for (int g = 0; g < TCM_G; ++g)
+                if (g < G) {
+                    *(float4*)(Tc + (((long)g * B + b) * n + j) * D + d) = v[g];
+                    const float om = omega_t[((long)g * B + b) * n + j];
+                    musum[g].x = fmaf(om, v[g].x, musum[g].x); musum[g].y = fmaf(om, v[g].y, musum[g].y);
+                    musum[g].z = fmaf(om, v[g].z, musum[g].z); musum[g].w = fmaf(om, v[g].w, musum[g].w);
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < TCM_G; ++g)
+            if (g < G) *(float4*)(chunk_sum + (((long)chunk * G + g) * B + b) * D + d) = musum[g];
+    }
+}
+
 // Streaming form of basd_teacher_center_multi for row-major teacher tokens (see teacher_mix_stream_kernel): scratch of
 // basd_teacher_center_stream_scratch_floats(G, B, n, D) floats.  BASD_EUNSUPPORTED: more than 4 groups, features not
 // contiguous.
@@ -1486,7 +1571,10 @@ int basd_teacher_center_stream(const void* const* tok_ptrs, int dtype, const flo
     BASD_CHECK_ARG((g0 == nullptr) == (g1 == nullptr) && (g0 == nullptr) == (glam == nullptr));
     if (G > TCM_G || sd != 1 || B > 65535 || (long)G * B > 65535) return BASD_EUNSUPPORTED;
     const int chunks = (n + TCS_ROWS - 1) / TCS_ROWS;
-    if (dtype == BASD_DTYPE_F32)
+    if (dtype == BASD_DTYPE_F32 && g0 == nullptr && D % 4 == 0 && sb % 4 == 0 && sn % 4 == 0 && (((uintptr_t)tc) & 15) == 0 &&
+        (((uintptr_t)scratch) & 15) == 0)
+        teacher_mix_stream_v4_kernel<<<dim3(chunks, B), 256, 0, stream>>>(tok_ptrs, mix, L, G, sb, sn, n, D, omega_t, tc, scratch);
+    else if (dtype == BASD_DTYPE_F32)
         teacher_mix_stream_kernel<float><<<dim3(chunks, B), 256, 0, stream>>>(tok_ptrs, mix, L, G, sb, sn, sd, n, D, g0, g1, glam, omega_t, tc, scratch);
     else if (dtype == BASD_DTYPE_BF16)
         teacher_mix_stream_kernel<__hip_bfloat16><<<dim3(chunks, B), 256, 0, stream>>>(tok_ptrs, mix, L, G, sb, sn, sd, n, D, g0, g1, glam, omega_t, tc, scratch);
