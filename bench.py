@@ -102,7 +102,24 @@ def one_step(mod, inp, leaves, logits, bucket):
     # RCCL over xGMI on the communicator's own stream: it runs underneath the next step's forward (whose teacher /
     # selector side does not depend on the optimizer step); no-op at world size 1
     bucket.all_reduce_mean(async_op=True)
+    if _SHADOW is not None:
+        # experiment (BASD_BENCH_SHADOW_ALLREDUCE=1, one GPU): a stand-in for that all-reduce -- a FIFTH stream that waits
+        # for the caller's and is joined by it one step later, with the 88 MB bucket copied twice on it (2 x (88 MB read +
+        # 88 MB written): about a ring all-reduce's HBM traffic per rank); "2": the two joins alone, no copies.
+        # Measured: 1.63 -> 2.1-2.2 ms per step either way -- it is the fifth stream with a cross-
+        # stream dependency that costs, not its work (the same wait issued by one of the loss's own four streams: 1.65).
+        side, tmp = _SHADOW
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(side)
+        side.wait_stream(cur)
+        if os.environ.get("BASD_BENCH_SHADOW_ALLREDUCE") == "1":
+            with torch.cuda.stream(side):
+                tmp[0].copy_(bucket.buffer)
+                tmp[1].copy_(tmp[0])
     return loss
+
+
+_SHADOW = None
 
 
 def cpu_baseline(cfg: str, shape: synth.LossShape, sample_batch: int, repeats: int = 3) -> dict:
@@ -234,6 +251,7 @@ def main() -> None:
                                     name=f"{shape.name} (synthetic teacher signal rank {args.teacher_rank})")
     batch = args.batch or shape.batch
     mod = build(shape, args.config, device)
+    global _SHADOW
     # per-rank minibatch (weak scaling): seed 1234 + rank, generated once, resident in HBM
     # cfg-5 (BASELINE.json configs[4]) hands bf16 features over; the kernels widen them and compute in fp32
     in_dtype = torch.bfloat16 if args.config == "cfg5" else torch.float32
@@ -242,6 +260,8 @@ def main() -> None:
     leaves = {k: v.detach().requires_grad_(True) for k, v in inp.student.items()}
     logits = inp.logits.detach().requires_grad_(True)
     bucket = ddp.FlatGradBucket(STUDENT_PARAMS[args.config], list(mod.parameters()), device)
+    if os.environ.get("BASD_BENCH_SHADOW_ALLREDUCE", "0") in ("1", "2") and world == 1:
+        _SHADOW = (torch.cuda.Stream(device=device), [torch.empty_like(bucket.buffer) for _ in range(2)])
     bucket.attach_grads([])             # the loss parameters' gradients live in the bucket (views, as in the trainer)
     multi_layer = shape.layers_t > 1
 
