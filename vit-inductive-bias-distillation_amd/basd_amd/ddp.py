@@ -11,6 +11,12 @@ import torch
 import torch.distributed as dist
 
 
+# test hook (BASD_FORCE_ALLREDUCE=1): run the collective at world size 1 as well -- what the N > 1 plumbing (communicator
+# stream, its events) costs a step can then be measured on one GPU
+import os as _os
+_FORCE_AT_WORLD_1 = _os.environ.get("BASD_FORCE_ALLREDUCE") == "1"
+
+
 class FlatGradBucket:
     """One contiguous fp32 buffer holding [student gradients | loss-module gradients]; a single
     all-reduce per step over RCCL/xGMI (backend "nccl" on ROCm) or gloo (CPU tests)."""
@@ -118,7 +124,9 @@ class FlatGradBucket:
     def all_reduce_mean(self, async_op: bool = False) -> None:
         """Mean over ranks of the current slot.  ``async_op``: only queued (on the communicator's own stream, behind
         the work already on the current stream); ``wait`` / ``next_slot`` join it."""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size() <= 1 and not _FORCE_AT_WORLD_1:
             return
         if self._avg_ok:       # decided once by ``_probe_avg``
             work = dist.all_reduce(self.buffer, op=dist.ReduceOp.AVG, async_op=True)       # RCCL averages in the reduction
